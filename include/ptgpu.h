@@ -1,0 +1,179 @@
+/*
+ * ptgpu.h -- C ABI of libptgpu, the MI355X (gfx950) replacement for the CPU tile pool of
+ * hpatjens/Pathtracer.
+ *
+ * What it replaces (paths relative to the reference checkout):
+ *   - src/window.rs:109-116,166-196   WorkerPool::new(8, |tile| tracer::render(tile, &backbuffer, scene))
+ *                                     + process(tile) x tiles + wait()      -> ptgpu_render()
+ *   - src/tracer.rs:618-647           tracer::render(WorkTile, &Backbuffer, Arc<RwLock<Scene>>)
+ *   - src/tracer.rs:200-283           Backbuffer {num_samples, pixels32, pixels8}, clear()
+ *                                                                            -> ptgpu_clear / ptgpu_read_*
+ *   - src/scene.rs:71-167             Scene / Sphere / Plane / Material / Sky data model (inputs only)
+ *                                                                            -> PtSceneDesc
+ *
+ * Plain C: pointers, sizes and PODs only.  All host memory stays owned by the caller; the library
+ * copies what it needs during the call and keeps no host pointer.  Every function returns 0 on
+ * success or a negative PtStatus; nothing aborts or throws across this boundary.  A handle is
+ * bound to one HIP device and must be driven from one host thread at a time.  There is NO CPU
+ * fallback: without a usable gfx950 device ptgpu_create fails with PT_ERR_NO_DEVICE.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = -1,
+    PT_ERR_NO_DEVICE = -2,        /* no HIP device / not gfx950 */
+    PT_ERR_HIP = -3,              /* a HIP runtime call failed; see ptgpu_last_error */
+    PT_ERR_NO_SCENE = -4,         /* render/read before ptgpu_upload_scene */
+    PT_ERR_QUEUE_OVERFLOW = -5,   /* a ray queue level exceeded its capacity (glass branching); raise branch_capacity */
+    PT_ERR_OUT_OF_MEMORY = -6
+} PtStatus;
+
+typedef struct { float x, y, z; } PtVec3;
+
+/* src/scene.rs:84-92 `enum Material`.  `color` is Emissive's radiance or Physically's reflectivity. */
+enum { PT_MAT_NONE = 0, PT_MAT_EMISSIVE = 1, PT_MAT_MIRROR = 2, PT_MAT_TRANSLUCENT = 3, PT_MAT_PHYSICALLY = 4 };
+typedef struct {
+    int32_t kind;
+    PtVec3 color;
+    float roughness;
+    float metalness;
+    float ior;
+} PtMaterial;
+
+/* src/scene.rs:128-133 `Sphere` */
+typedef struct { PtVec3 origin; float radius; PtMaterial material; } PtSphere;
+/* src/scene.rs:95-102 `Plane`; `normal` is what Plane::new computed (scene.rs:106) */
+typedef struct { PtVec3 origin, u, v; PtMaterial material; PtVec3 normal; } PtPlane;
+
+/* src/tracer.rs:43-48 `enum ToneMapping` */
+enum { PT_TONE_CLAMP = 0, PT_TONE_REINHARD = 1, PT_TONE_EXPOSURE = 2 };
+/* src/tracer.rs:50-66 `Camera` with its private `CameraPlane` flattened in */
+typedef struct {
+    PtVec3 plane_origin, plane_u, plane_v;
+    PtVec3 position;
+    float width, height, z_near;
+    int32_t tone_mapping;
+    float exposure;          /* ToneMapping::Exposure(value) */
+    float iso;
+} PtCamera;
+
+/* src/scene.rs:71-75 `enum Sky`.  HDRI with pixels == NULL is the "texture not loaded yet" state
+ * (tracer.rs:579: white). */
+enum { PT_SKY_CONSTANT = 0, PT_SKY_HDRI = 1 };
+typedef struct {
+    int32_t kind;
+    PtVec3 radiance;
+    const float *pixels;     /* width*height*3 f32, row-major (src/scene.rs:7-13) */
+    uint64_t width, height;
+} PtSky;
+
+/* src/scene.rs:151-160 `Scene` + src/tracer.rs:8-13 `ImageSettings`.  Primitive ids used by every id
+ * buffer follow find_scene_hit's iteration order (src/scene.rs:266,280): spheres, emissive_spheres,
+ * planes, emissive_planes; 0xFFFFFFFF = miss. */
+typedef struct {
+    uint32_t width, height;
+    int32_t sub_pixel_sampling;
+    PtCamera camera;
+    PtSky sky;
+    const PtSphere *spheres;          uint64_t n_spheres;
+    const PtPlane *planes;            uint64_t n_planes;
+    const PtSphere *emissive_spheres; uint64_t n_emissive_spheres;
+    const PtPlane *emissive_planes;   uint64_t n_emissive_planes;
+} PtSceneDesc;
+
+enum { PT_ACCEL_AUTO = 0, PT_ACCEL_BRUTE_FORCE = 1, PT_ACCEL_BVH = 2 };
+
+/* Knobs that are constants in the reference (tracer.rs:633 depth 4; common.rs:28 seed) or that only
+ * exist because the work is on GPUs.  Zero-initialise and then call ptgpu_default_config. */
+typedef struct {
+    int32_t device;               /* HIP device ordinal */
+    uint32_t seed;                /* counter-RNG key */
+    int32_t max_depth;            /* recursion depth passed to trace_radiance (reference: 4); 1..24 */
+    int32_t sub_pixel_override;   /* -1: use scene.sub_pixel_sampling; 0/1: force (the reference parser cannot express false) */
+    uint32_t shard_index;         /* this handle renders global sample indices s with s % shard_count == shard_index */
+    uint32_t shard_count;
+    uint32_t samples_per_batch;   /* samples per pixel traced per pipeline pass; 0 = auto */
+    uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records; 0 = 16 */
+    int32_t accel;                /* PT_ACCEL_* */
+    int32_t fuse_trace_shade;     /* 1: one kernel per level does intersection + shading; 0: two kernels; -1: auto */
+    int32_t profile_events;       /* 1: bracket kernels with HIP events and report per-kernel time in PtStats */
+} PtConfig;
+
+enum { PT_KERNEL_RAYGEN = 0, PT_KERNEL_TRACE = 1, PT_KERNEL_SHADE = 2, PT_KERNEL_TRACE_SHADE = 3,
+       PT_KERNEL_TERMINAL = 4, PT_KERNEL_GATHER = 5, PT_KERNEL_RESOLVE = 6, PT_KERNEL_COUNT = 8 };
+
+typedef struct {
+    uint64_t samples;                         /* pixel-samples accumulated by this handle since clear */
+    uint64_t rays;                            /* nearest-hit queries (primary + bounce + shadow) since clear */
+    uint64_t records;                         /* queue records processed over all levels since clear */
+    uint64_t bvh_nodes, bvh_leaf_prims;       /* size of the current BVH (0 for brute force) */
+    uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */
+    double kernel_ms[PT_KERNEL_COUNT];        /* since clear (profile_events only) */
+    uint64_t device_bytes;                    /* device memory held by the handle */
+} PtStats;
+
+typedef struct PtHandle PtHandle;
+
+void ptgpu_default_config(PtConfig *cfg);
+
+/* Replaces WorkerPool::new + Backbuffer::new (src/window.rs:104-116). */
+int ptgpu_create(const PtConfig *cfg, PtHandle **out);
+void ptgpu_destroy(PtHandle *h);
+
+/* Called wherever the reference replaces `*scene` and clears the backbuffer (src/window.rs:130-163):
+ * flattens the scene into device buffers, (re)builds the BVH, resizes and zeroes the accumulators. */
+int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *scene);
+
+/* Backbuffer::clear (src/tracer.rs:242-256): zero pixels32/pixels8, sample count back to 0. */
+int ptgpu_clear(PtHandle *h);
+
+/* Replaces n_samples frames of the tile fan-out + barrier (src/window.rs:166-196): adds n_samples
+ * samples per pixel to the accumulators.  Work is enqueued on the handle's stream; ptgpu_sync or any
+ * ptgpu_read_* waits for it. */
+int ptgpu_render(PtHandle *h, uint32_t n_samples);
+int ptgpu_sync(PtHandle *h);
+
+/* Backbuffer.pixels32 (u32 x3 sums, row-major, row 0 = bottom) and the number of samples summed. */
+int ptgpu_read_pixels32(PtHandle *h, uint32_t *out, uint64_t *num_samples);
+/* Backbuffer.pixels8 exactly as assign_pixel8_unsafe leaves it after the last frame
+ * (src/tracer.rs:271-282): min(255, iso/100 * sum / num_samples) truncated; what glDrawPixels shows
+ * (src/window.rs:205-210). */
+int ptgpu_read_pixels8(PtHandle *h, uint8_t *out);
+
+/* Parity hook: primitive id hit by the primary ray of every pixel for one global sample index. */
+int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out);
+
+/* Multi-GPU combine: the device address of this handle's u32 accumulator (width*height*3 words) so a
+ * host can all-reduce it in place (RCCL / torch.distributed), then set the global sample count. */
+int ptgpu_device_pixels32(PtHandle *h, void **device_ptr, uint64_t *n_words);
+int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples);
+/* The hipStream_t all work of this handle is enqueued on (as void*), for event timing by the caller. */
+int ptgpu_stream(PtHandle *h, void **stream);
+
+int ptgpu_get_stats(PtHandle *h, PtStats *out);
+const char *ptgpu_last_error(PtHandle *h);
+
+/* What the Rust host computes with hmath before the scene reaches this library; provided for C/C++/
+ * Python hosts.  Camera::new (src/tracer.rs:69-96) and Plane::new's normal (src/scene.rs:106). */
+void ptgpu_camera_new(PtVec3 position, PtVec3 target, PtVec3 up, float width, float height, float z_near,
+                      int32_t tone_mapping, float exposure, float iso, PtCamera *out);
+void ptgpu_plane_normal(PtVec3 u, PtVec3 v, PtVec3 *out);
+void ptgpu_plane_normals(PtPlane *planes, uint64_t n);   /* fills planes[i].normal from u and v */
+
+/* Device-side evaluation of one deterministic math function over n arguments (test hook for the
+ * sin/cos/pow/exp/acos/atan2 replacements the kernels use): fn 0 sin, 1 cos, 2 pow, 3 exp, 4 acos, 5 atan2. */
+int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,263 @@
+"""ctypes binding of libptgpu's C ABI (include/ptgpu.h) and a small object wrapper.
+
+The wrapper mirrors how the reference's window loop drives the path (reference src/window.rs:104-213):
+create once, upload a scene whenever it changes, render n frames' worth of samples, read the backbuffer.
+There is no CPU path behind it: every call ends in the HIP library and fails loudly without it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import scene as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+
+PT_KERNEL_COUNT = 8
+KERNEL_NAMES = ["raygen", "trace", "shade", "trace_shade", "terminal", "gather", "resolve", "unused"]
+STATUS = {0: "PT_OK", -1: "PT_ERR_INVALID_ARGUMENT", -2: "PT_ERR_NO_DEVICE", -3: "PT_ERR_HIP", -4: "PT_ERR_NO_SCENE",
+          -5: "PT_ERR_QUEUE_OVERFLOW", -6: "PT_ERR_OUT_OF_MEMORY"}
+ACCEL_AUTO, ACCEL_BRUTE_FORCE, ACCEL_BVH = 0, 1, 2
+
+
+class PtVec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class PtCamera(C.Structure):
+    _fields_ = [("plane_origin", PtVec3), ("plane_u", PtVec3), ("plane_v", PtVec3), ("position", PtVec3),
+                ("width", C.c_float), ("height", C.c_float), ("z_near", C.c_float), ("tone_mapping", C.c_int32),
+                ("exposure", C.c_float), ("iso", C.c_float)]
+
+
+class PtSky(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("radiance", PtVec3), ("pixels", C.c_void_p), ("width", C.c_uint64), ("height", C.c_uint64)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sub_pixel_sampling", C.c_int32), ("camera", PtCamera),
+                ("sky", PtSky),
+                ("spheres", C.c_void_p), ("n_spheres", C.c_uint64),
+                ("planes", C.c_void_p), ("n_planes", C.c_uint64),
+                ("emissive_spheres", C.c_void_p), ("n_emissive_spheres", C.c_uint64),
+                ("emissive_planes", C.c_void_p), ("n_emissive_planes", C.c_uint64)]
+
+
+class PtConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("seed", C.c_uint32), ("max_depth", C.c_int32), ("sub_pixel_override", C.c_int32),
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("samples_per_batch", C.c_uint32),
+                ("branch_capacity", C.c_uint32), ("accel", C.c_int32), ("fuse_trace_shade", C.c_int32),
+                ("profile_events", C.c_int32)]
+
+
+class PtStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("records", C.c_uint64), ("bvh_nodes", C.c_uint64),
+                ("bvh_leaf_prims", C.c_uint64), ("kernel_launches", C.c_uint64 * PT_KERNEL_COUNT),
+                ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64)]
+
+
+class PtGpuError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{STATUS.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libptgpu.so (built in-tree by __graft_entry__.build()).  Raises if it is missing: there is no
+    fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.ptgpu_default_config.argtypes = [C.POINTER(PtConfig)]
+    lib.ptgpu_default_config.restype = None
+    lib.ptgpu_create.argtypes = [C.POINTER(PtConfig), C.POINTER(H)]
+    lib.ptgpu_destroy.argtypes = [H]
+    lib.ptgpu_destroy.restype = None
+    lib.ptgpu_upload_scene.argtypes = [H, C.POINTER(PtSceneDesc)]
+    lib.ptgpu_clear.argtypes = [H]
+    lib.ptgpu_render.argtypes = [H, C.c_uint32]
+    lib.ptgpu_sync.argtypes = [H]
+    lib.ptgpu_read_pixels32.argtypes = [H, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.ptgpu_read_pixels8.argtypes = [H, C.c_void_p]
+    lib.ptgpu_render_primary_ids.argtypes = [H, C.c_uint32, C.c_void_p]
+    lib.ptgpu_device_pixels32.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.ptgpu_set_num_samples.argtypes = [H, C.c_uint64]
+    lib.ptgpu_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.ptgpu_get_stats.argtypes = [H, C.POINTER(PtStats)]
+    lib.ptgpu_last_error.argtypes = [H]
+    lib.ptgpu_last_error.restype = C.c_char_p
+    lib.ptgpu_camera_new.argtypes = [PtVec3, PtVec3, PtVec3, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float,
+                                     C.POINTER(PtCamera)]
+    lib.ptgpu_camera_new.restype = None
+    lib.ptgpu_plane_normal.argtypes = [PtVec3, PtVec3, C.POINTER(PtVec3)]
+    lib.ptgpu_plane_normal.restype = None
+    lib.ptgpu_plane_normals.argtypes = [C.c_void_p, C.c_uint64]
+    lib.ptgpu_plane_normals.restype = None
+    lib.ptgpu_eval_math.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    for name in ("ptgpu_create", "ptgpu_upload_scene", "ptgpu_clear", "ptgpu_render", "ptgpu_sync", "ptgpu_read_pixels32",
+                 "ptgpu_read_pixels8", "ptgpu_render_primary_ids", "ptgpu_device_pixels32", "ptgpu_set_num_samples",
+                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _v(t) -> PtVec3:
+    return PtVec3(float(t[0]), float(t[1]), float(t[2]))
+
+
+def default_config(**overrides) -> PtConfig:
+    cfg = PtConfig()
+    load_library().ptgpu_default_config(C.byref(cfg))
+    for k, val in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, val)
+    return cfg
+
+
+def camera_new(cam: S.Camera) -> PtCamera:
+    """Camera::new (reference src/tracer.rs:69-96) as computed by the library's host code."""
+    out = PtCamera()
+    load_library().ptgpu_camera_new(_v(cam.position), _v(cam.target), _v(cam.up), cam.width, cam.height, cam.z_near,
+                                    cam.tone_mapping, cam.exposure, cam.iso, C.byref(out))
+    return out
+
+
+class SceneDesc:
+    """A PtSceneDesc plus the numpy buffers it points into (kept alive with it)."""
+
+    def __init__(self, scene: S.Scene):
+        lib = load_library()
+        self.arrays = list(scene.arrays())
+        for k in (1, 3):  # Plane::new's normal (reference src/scene.rs:106)
+            if len(self.arrays[k]):
+                self.arrays[k] = self.arrays[k].copy()
+                lib.ptgpu_plane_normals(self.arrays[k].ctypes.data, len(self.arrays[k]))
+        d = PtSceneDesc()
+        d.width, d.height = scene.image_settings.width, scene.image_settings.height
+        d.sub_pixel_sampling = 1 if scene.image_settings.sub_pixel_sampling else 0
+        d.camera = camera_new(scene.camera)
+        d.sky.kind = scene.sky.kind
+        d.sky.radiance = _v(scene.sky.radiance)
+        self.sky_pixels = None
+        if scene.sky.kind == S.SKY_HDRI and scene.sky.pixels is not None:
+            self.sky_pixels = np.ascontiguousarray(scene.sky.pixels, dtype=np.float32)
+            d.sky.pixels = self.sky_pixels.ctypes.data
+            d.sky.height, d.sky.width = self.sky_pixels.shape[0], self.sky_pixels.shape[1]
+        sp, pl, es, ep = self.arrays
+        d.spheres, d.n_spheres = (sp.ctypes.data if len(sp) else None), len(sp)
+        d.planes, d.n_planes = (pl.ctypes.data if len(pl) else None), len(pl)
+        d.emissive_spheres, d.n_emissive_spheres = (es.ctypes.data if len(es) else None), len(es)
+        d.emissive_planes, d.n_emissive_planes = (ep.ctypes.data if len(ep) else None), len(ep)
+        self.desc = d
+
+
+class PtGpu:
+    """One handle = one GPU's share of the render (reference: the WorkerPool + Backbuffer pair of
+    src/window.rs:104-116)."""
+
+    def __init__(self, cfg: Optional[PtConfig] = None, **overrides):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config(**overrides)
+        self.h = C.c_void_p()
+        rc = self.lib.ptgpu_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise PtGpuError(rc, "ptgpu_create failed (a gfx950 GPU is required)")
+        self.width = self.height = 0
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise PtGpuError(rc, (self.lib.ptgpu_last_error(self.h) or b"").decode())
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.ptgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload_scene(self, scene: S.Scene) -> None:
+        sd = SceneDesc(scene)
+        self._chk(self.lib.ptgpu_upload_scene(self.h, C.byref(sd.desc)))
+        self.width, self.height = scene.image_settings.width, scene.image_settings.height
+
+    def clear(self) -> None:
+        self._chk(self.lib.ptgpu_clear(self.h))
+
+    def render(self, n_samples: int) -> None:
+        self._chk(self.lib.ptgpu_render(self.h, int(n_samples)))
+
+    def sync(self) -> None:
+        self._chk(self.lib.ptgpu_sync(self.h))
+
+    def read_pixels32(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint32)
+        n = C.c_uint64()
+        self._chk(self.lib.ptgpu_read_pixels32(self.h, out.ctypes.data, C.byref(n)))
+        return out, int(n.value)
+
+    def read_pixels8(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._chk(self.lib.ptgpu_read_pixels8(self.h, out.ctypes.data))
+        return out
+
+    def primary_ids(self, sample_index: int = 0) -> np.ndarray:
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        self._chk(self.lib.ptgpu_render_primary_ids(self.h, int(sample_index), out.ctypes.data))
+        return out
+
+    def device_pixels32(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.ptgpu_device_pixels32(self.h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def set_num_samples(self, n: int) -> None:
+        self._chk(self.lib.ptgpu_set_num_samples(self.h, int(n)))
+
+    def stream(self) -> int:
+        p = C.c_void_p()
+        self._chk(self.lib.ptgpu_stream(self.h, C.byref(p)))
+        return int(p.value or 0)
+
+    def stats(self) -> dict:
+        st = PtStats()
+        self._chk(self.lib.ptgpu_get_stats(self.h, C.byref(st)))
+        return {
+            "samples": st.samples, "rays": st.rays, "records": st.records, "bvh_nodes": st.bvh_nodes,
+            "bvh_leaf_prims": st.bvh_leaf_prims, "device_bytes": st.device_bytes,
+            "kernel_launches": {KERNEL_NAMES[k]: st.kernel_launches[k] for k in range(PT_KERNEL_COUNT)},
+            "kernel_ms": {KERNEL_NAMES[k]: st.kernel_ms[k] for k in range(PT_KERNEL_COUNT)},
+        }
+
+    def eval_math(self, fn: int, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.empty_like(a)
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            bp = b.ctypes.data
+        self._chk(self.lib.ptgpu_eval_math(self.h, fn, a.ctypes.data, bp, out.ctypes.data, a.size))
+        return out

@@ -1,0 +1,251 @@
+// pt_bvh_build.h -- host-side BVH construction (binned SAH, depth-capped) over the flattened primitives.
+//
+// The reference scans all primitives per ray (reference src/scene.rs:263-297); this structure exists only so
+// that scan can skip primitives the ray cannot reach.  Boxes therefore bound the region in which the
+// reference's OWN tests can accept a hit, not the ideal geometry:
+//   * sphere (src/scene.rs:169-221): centre +- radius;
+//   * plane  (src/scene.rs:223-261): the set {x in the plane : 0 <= (x-s).un <= |u|, 0 <= (x-s).vn <= |v|},
+//     which is the u,v parallelogram only when u is perpendicular to v; its four corners are solved for here;
+//   * every box is then grown by `pad` = 2^-16 of the largest coordinate magnitude in the scene (camera
+//     included), orders of magnitude above the f32 rounding of num/denum, p + t*d and the slab test for rays
+//     that start within a few scene diameters.
+// Planes whose normal is not finite can never be hit (the In test fails on NaN) and are left out; planes with
+// a finite normal but unusable axes (zero or parallel u, v) cannot be bounded and go to the `always` list,
+// which the traversal tests for every ray.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "pt_bvh.h"
+
+namespace pt {
+
+struct BvhBuilder {
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> prims;   // leaf primitive ids
+    std::vector<uint32_t> always;  // primitives tested for every ray
+    int max_depth_seen = 0;
+
+    struct Box {
+        double lo[3], hi[3];
+        void reset() { for (int k = 0; k < 3; ++k) { lo[k] = 1e300; hi[k] = -1e300; } }
+        void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+        void grow(const double p[3]) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+        double area() const {
+            double d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+            if (d0 < 0 || d1 < 0 || d2 < 0) return 0.0;
+            return 2.0 * (d0 * d1 + d1 * d2 + d2 * d0);
+        }
+    };
+
+    struct BuildNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+    std::vector<Box> pbox;
+    std::vector<double> pcent;  // 3 per primitive
+    std::vector<uint32_t> idx;
+    std::vector<BuildNode> bn;
+    double pad = 0.0;
+
+    static bool finite3(double a, double b, double c) { return std::isfinite(a) && std::isfinite(b) && std::isfinite(c); }
+
+    void build(const std::vector<float4> &sph, const std::vector<float4> &pln, V3 cam_pos, V3 cam_plane_origin) {
+        const uint32_t n_sph = (uint32_t)sph.size(), n_pl = (uint32_t)(pln.size() / 4);
+        const uint32_t n = n_sph + n_pl;
+        pbox.resize(n);
+        pcent.resize(3 * (size_t)n);
+        idx.clear();
+        idx.reserve(n);
+        double M = 0.0;
+        auto track = [&](double v) { if (std::isfinite(v)) M = std::max(M, std::fabs(v)); };
+        track(cam_pos.x); track(cam_pos.y); track(cam_pos.z);
+        track(cam_plane_origin.x); track(cam_plane_origin.y); track(cam_plane_origin.z);
+        for (uint32_t i = 0; i < n_sph; ++i) {
+            const float4 s = sph[i];
+            Box &b = pbox[i];
+            double r = std::fabs((double)s.w);
+            if (!finite3(s.x, s.y, s.z) || !std::isfinite(r)) { always.push_back(i); continue; }
+            b.lo[0] = s.x - r; b.lo[1] = s.y - r; b.lo[2] = s.z - r;
+            b.hi[0] = s.x + r; b.hi[1] = s.y + r; b.hi[2] = s.z + r;
+            idx.push_back(i);
+        }
+        for (uint32_t k = 0; k < n_pl; ++k) {
+            const float4 q0 = pln[4 * k], q1 = pln[4 * k + 1], q2 = pln[4 * k + 2], q3 = pln[4 * k + 3];
+            const uint32_t id = n_sph + k;
+            if (!finite3(q0.x, q0.y, q0.z)) continue;  // NaN normal: never accepted
+            double s[3] = {q0.w, q1.x, q1.y};
+            double un[3] = {q1.z, q1.w, q2.x}, vn[3] = {q2.z, q2.w, q3.x};
+            double ul = q2.y, vl = q3.y;
+            double c = un[0] * vn[0] + un[1] * vn[1] + un[2] * vn[2];
+            bool ok = finite3(s[0], s[1], s[2]) && finite3(un[0], un[1], un[2]) && finite3(vn[0], vn[1], vn[2]) && std::isfinite(ul) &&
+                      std::isfinite(vl) && std::fabs(c) < 0.999;
+            if (!ok) { always.push_back(id); continue; }
+            Box &b = pbox[id];
+            b.reset();
+            double inv = 1.0 / (1.0 - c * c);
+            for (int ia = 0; ia < 2; ++ia)
+                for (int ib = 0; ib < 2; ++ib) {
+                    double a = ia ? ul : 0.0, bb = ib ? vl : 0.0;
+                    double alpha = (a - bb * c) * inv, beta = (bb - a * c) * inv;
+                    double p[3];
+                    for (int d = 0; d < 3; ++d) p[d] = s[d] + alpha * un[d] + beta * vn[d];
+                    b.grow(p);
+                }
+            idx.push_back(id);
+        }
+        for (uint32_t i : idx) {
+            const Box &b = pbox[i];
+            for (int d = 0; d < 3; ++d) {
+                pcent[3 * (size_t)i + d] = 0.5 * (b.lo[d] + b.hi[d]);
+                track(b.lo[d]); track(b.hi[d]);
+            }
+        }
+        pad = std::ldexp(std::max(M, 1e-30), -16);
+        std::sort(always.begin(), always.end());
+
+        nodes.clear();
+        prims.clear();
+        bn.clear();
+        if (idx.empty()) {  // nothing boundable: a root with two empty children
+            BvhNode root{};
+            root.c0 = BVH_EMPTY; root.c1 = BVH_EMPTY;
+            nodes.push_back(root);
+            return;
+        }
+        bn.reserve(idx.size());
+        build_range(0, (uint32_t)idx.size(), 0);
+        flatten();
+    }
+
+    Box range_box(uint32_t first, uint32_t count) const {
+        Box b; b.reset();
+        for (uint32_t i = first; i < first + count; ++i) b.grow(pbox[idx[i]]);
+        return b;
+    }
+
+    int32_t build_range(uint32_t first, uint32_t count, int depth) {
+        max_depth_seen = std::max(max_depth_seen, depth);
+        const int32_t me = (int32_t)bn.size();
+        bn.emplace_back();
+        bn[me].box = range_box(first, count);
+        bn[me].first = first; bn[me].count = count;
+        if (count <= (uint32_t)BVH_MAX_LEAF) return me;
+        // Children sit one level deeper; a leaf holds BVH_MAX_LEAF.  Force a median split when SAH imbalance
+        // could otherwise exceed the traversal stack.
+        const int remaining = (BVH_STACK - 2) - depth;
+        bool force_median = remaining < 1 || (remaining < 40 && (uint64_t)count > ((uint64_t)BVH_MAX_LEAF << (remaining > 0 ? remaining - 1 : 0)));
+        Box cb; cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) cb.grow(&pcent[3 * (size_t)idx[i]]);
+        int axis = 0;
+        double ext = -1.0;
+        for (int d = 0; d < 3; ++d) if (cb.hi[d] - cb.lo[d] > ext) { ext = cb.hi[d] - cb.lo[d]; axis = d; }
+        uint32_t mid = first + count / 2;
+        bool split_done = false;
+        if (!force_median && ext > 0.0) {
+            constexpr int NB = 16;
+            double best_cost = 1e300;
+            int best_axis = -1, best_bin = -1;
+            for (int d = 0; d < 3; ++d) {
+                double lo = cb.lo[d], w = cb.hi[d] - cb.lo[d];
+                if (!(w > 0.0)) continue;
+                Box bb[NB]; uint32_t bc[NB];
+                for (int b = 0; b < NB; ++b) { bb[b].reset(); bc[b] = 0; }
+                double scale = NB / w;
+                for (uint32_t i = first; i < first + count; ++i) {
+                    uint32_t p = idx[i];
+                    int b = (int)((pcent[3 * (size_t)p + d] - lo) * scale);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    bb[b].grow(pbox[p]); bc[b]++;
+                }
+                double right_area[NB]; uint32_t right_cnt[NB];
+                Box acc; acc.reset(); uint32_t cnt = 0;
+                for (int b = NB - 1; b >= 1; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.area(); right_cnt[b] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    acc.grow(bb[b]); cnt += bc[b];
+                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                    double cost = acc.area() * cnt + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = d; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                double lo = cb.lo[best_axis], scale = NB / (cb.hi[best_axis] - cb.lo[best_axis]);
+                auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t p) {
+                    int b = (int)((pcent[3 * (size_t)p + best_axis] - lo) * scale);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - idx.begin());
+                split_done = mid > first && mid < first + count;
+            }
+        }
+        if (!split_done) {  // object median along the widest centroid axis (or plain halves when all coincide)
+            mid = first + count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count, [&](uint32_t a, uint32_t b) {
+                double ca = pcent[3 * (size_t)a + axis], cb2 = pcent[3 * (size_t)b + axis];
+                return ca < cb2 || (ca == cb2 && a < b);
+            });
+        }
+        int32_t l = build_range(first, mid - first, depth + 1);
+        int32_t r = build_range(mid, first + count - mid, depth + 1);
+        bn[me].left = l; bn[me].right = r;
+        return me;
+    }
+
+    static float down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
+    static float up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
+
+    int32_t child_ref(int32_t b, std::vector<int32_t> &inner_index) {
+        const BuildNode &n = bn[b];
+        if (n.left < 0) {  // leaf
+            uint32_t first = (uint32_t)prims.size();
+            std::vector<uint32_t> ids(idx.begin() + n.first, idx.begin() + n.first + n.count);
+            std::sort(ids.begin(), ids.end());
+            prims.insert(prims.end(), ids.begin(), ids.end());
+            return ~(int32_t)((first << 3) | (n.count - 1));
+        }
+        return inner_index[b];
+    }
+
+    void set_box(BvhNode &N, int which, const Box &b) {
+        float lo[3], hi[3];
+        for (int d = 0; d < 3; ++d) { lo[d] = down(b.lo[d] - pad); hi[d] = up(b.hi[d] + pad); }
+        if (which == 0) { N.a = make_float4(lo[0], lo[1], lo[2], hi[0]); N.b.x = hi[1]; N.b.y = hi[2]; }
+        else { N.b.z = lo[0]; N.b.w = lo[1]; N.c = make_float4(lo[2], hi[0], hi[1], hi[2]); }
+    }
+
+    void flatten() {
+        // inner build nodes get device node indices in breadth-first order, so the top of the tree is contiguous
+        std::vector<int32_t> inner_index(bn.size(), -1), order;
+        if (bn[0].left < 0) {  // a single leaf: wrap it in a root
+            BvhNode root{};
+            std::vector<int32_t> none;
+            set_box(root, 0, bn[0].box);
+            root.c0 = child_ref(0, none);
+            root.c1 = BVH_EMPTY;
+            nodes.push_back(root);
+            return;
+        }
+        order.push_back(0);
+        inner_index[0] = 0;
+        for (size_t k = 0; k < order.size(); ++k) {
+            const BuildNode &n = bn[order[k]];
+            for (int32_t c : {n.left, n.right})
+                if (bn[c].left >= 0) { inner_index[c] = (int32_t)order.size(); order.push_back(c); }
+        }
+        nodes.resize(order.size());
+        for (size_t k = 0; k < order.size(); ++k) {
+            const BuildNode &n = bn[order[k]];
+            BvhNode N{};
+            set_box(N, 0, bn[n.left].box);
+            set_box(N, 1, bn[n.right].box);
+            N.c0 = child_ref(n.left, inner_index);
+            N.c1 = child_ref(n.right, inner_index);
+            nodes[k] = N;
+        }
+    }
+};
+
+}  // namespace pt

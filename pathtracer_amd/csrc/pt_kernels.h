@@ -1,0 +1,326 @@
+// pt_kernels.h -- the wavefront pipeline that replaces the reference's CPU tile pool
+// (reference src/window.rs:166-196 fan-out + src/tracer.rs:618-647 render + :448-584 trace_radiance).
+//
+// One pipeline pass traces `S` pixel-samples.  The recursion of trace_radiance becomes a forward sweep
+// over path-tree levels followed by a backward sweep:
+//
+//   level l holds one RECORD per trace_radiance call at recursion depth max_depth - l:
+//     ray    (origin, direction, sample id, path-node id, parent record + child slot)
+//     node   (kind, coefficients)            written by the shade step of that level
+//     val0/1 (radiance of child 0 / child 1)  written by the children (leaves: at once, inner nodes: on the
+//                                             backward sweep)
+//   forward : raygen -> for l = 0..D-1: [trace, shade] (or the fused trace_shade) -> terminal (level D)
+//   backward: gather for l = D-1..1 (node_value -> parent's val slot) -> resolve (level 0: tone map, gamma,
+//             quantise, integer accumulate)
+//
+// Evaluating every node from its children's final values reproduces the reference's floating-point
+// association exactly (k4*(k3*(k2*(k1*L))) rather than a running throughput product), glass branching
+// included, and needs no float atomics: every val slot has exactly one writer.
+//
+// Queues: each level is split in 64 shards (one per lane of a wave, so a wave can scan the shard counts
+// with one load).  A wave appends all its children with ONE returning atomic on its own shard's counter
+// (ballot + prefix popcount); 64 counters keep that atomic far from the ~90 atomics/us a single word
+// sustains.  Record index = shard * shard_cap + offset.
+#pragma once
+
+#include "pt_scene.h"
+#include "pt_bvh.h"
+
+namespace pt {
+
+constexpr int NSHARD = 64;
+constexpr int BLOCK = 256;
+
+struct Level {
+    float4 *rayA;       // (origin.xyz, dir.x)
+    float4 *rayB;       // (dir.y, dir.z, bits(sample id), bits(path node))
+    uint32_t *parent;   // (parent record index << 1) | child slot
+    uint32_t *hitprim;  // primitive id of the nearest hit (unfused pipeline only)
+    uint32_t *meta;     // node kind
+    float4 *coef;       // node coefficients (xyz, w)
+    float4 *val0;       // radiance of child 0
+    float4 *val1;       // radiance of child 1 (glass reflection)
+    uint32_t *count;    // [NSHARD] records per shard
+    uint32_t shard_cap;
+};
+
+struct PassParams {
+    uint32_t n_pixels;        // P
+    uint32_t sample_first;    // global sample index of local sample 0 of this pass
+    uint32_t sample_stride;   // shard_count
+};
+
+// device-side counters (one allocation): [0] overflow flag, [1] pad, [2..3] rays (u64), [4..5] records (u64)
+struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays; unsigned long long records; };
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// ---- shard bookkeeping ------------------------------------------------------------------------------
+struct TileMap { uint32_t cnt, incl, total; };  // per lane: records and inclusive tile prefix of shard `lane`
+
+__device__ __forceinline__ TileMap tile_map(const Level &L) {
+    TileMap m;
+    uint32_t lane = lane_id();
+    uint32_t c = L.count[lane];
+    m.cnt = c < L.shard_cap ? c : L.shard_cap;
+    uint32_t incl = (m.cnt + 63u) >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    m.incl = incl;
+    m.total = __shfl(incl, 63);
+    return m;
+}
+// Record handled by this lane in wave-tile `w` (wave-uniform); false for padding lanes.
+__device__ __forceinline__ bool tile_record(const TileMap &m, const Level &L, uint32_t w, uint32_t &idx) {
+    uint32_t q = (uint32_t)__popcll(__ballot(m.incl <= w));  // shards entirely before tile w
+    uint32_t before = __shfl(m.incl, (int)((q + 63u) & 63u));
+    if (q == 0) before = 0;
+    uint32_t cq = __shfl(m.cnt, (int)q);
+    uint32_t off = (w - before) * 64u + lane_id();
+    idx = q * L.shard_cap + off;
+    return off < cq;
+}
+
+// Reserve room in `L` for this wave's children; every lane of the wave must call it.
+__device__ __forceinline__ void wave_append(const Level &L, uint32_t shard, bool &has0, bool &has1, uint32_t &i0, uint32_t &i1,
+                                            Counters *ctr) {
+    unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
+    uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), total = n0 + n1;
+    i0 = i1 = 0;
+    if (total == 0) return;
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(&L.count[shard], total);
+    base = __shfl(base, 0);
+    if (base + total > L.shard_cap) {  // never drop silently: the host turns this into PT_ERR_QUEUE_OVERFLOW
+        if (lane_id() == 0) atomicOr(&ctr->overflow, 1u);
+        has0 = has1 = false;
+        return;
+    }
+    unsigned long long lt = (1ull << lane_id()) - 1ull;
+    i0 = shard * L.shard_cap + base + (uint32_t)__popcll(m0 & lt);
+    i1 = shard * L.shard_cap + base + n0 + (uint32_t)__popcll(m1 & lt);
+}
+
+__device__ __forceinline__ uint32_t my_shard() { return (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (NSHARD - 1); }
+__device__ __forceinline__ uint32_t wave_global() { return blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t waves_in_grid() { return gridDim.x * (BLOCK / 64); }
+
+__device__ __forceinline__ uint32_t sample_key_of(const DevScene &sc, const PassParams &pp, uint32_t sid) {
+    uint32_t pixel = sid % pp.n_pixels, s_local = sid / pp.n_pixels;
+    return rng_sample_key(sc.seed, pixel, pp.sample_first + s_local * pp.sample_stride);
+}
+
+// ---- nearest hit (linear scan or BVH) -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t) {
+    if (sc.bvh_nodes) return bvh_nearest(sc, o, d, t);
+    return nearest_brute(sc.sph, sc.n_sph, sc.pln, sc.n_pl, o, d, t);
+}
+
+// ---- raygen: reference src/tracer.rs:125-142,628-631 -------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, Level L0, PassParams pp, uint32_t n_records) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_records; i += gridDim.x * BLOCK) {
+        uint32_t pixel = i % pp.n_pixels;
+        uint32_t x = pixel % sc.width, y = pixel / sc.width;
+        uint32_t skey = sample_key_of(sc, pp, i);
+        V3 o, d;
+        pinhole_ray(sc, x, y, skey, o, d);
+        L0.rayA[i] = make_float4(o.x, o.y, o.z, d.x);
+        L0.rayB[i] = make_float4(d.y, d.z, u2f(i), u2f(1u));
+    }
+}
+
+// ---- trace: reference src/scene.rs:263-297 ------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
+    TileMap m = tile_map(L);
+    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
+        uint32_t i;
+        if (!tile_record(m, L, w, i)) continue;
+        float4 a = L.rayA[i], b = L.rayB[i];
+        float t;
+        L.hitprim[i] = nearest_hit(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), t);
+    }
+}
+
+// ---- shade (optionally fused with trace): reference src/tracer.rs:494-583 -------------------------------------
+// `level` is this level's index l; the children go to Lnext (level l+1).  At l >= 1 a leaf stores its radiance
+// straight into its parent's val slot; at l == 0 it keeps it in its own coef for the resolve step.
+template <bool FUSED>
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
+                                                 Counters *ctr) {
+    TileMap m = tile_map(L);
+    const uint32_t shard = my_shard();
+    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
+        uint32_t i;
+        bool valid = tile_record(m, L, w, i);
+        NodeOut out;
+        out.n_children = 0;
+        uint32_t sid = 0, node = 0;
+        if (valid) {
+            float4 a = L.rayA[i], b = L.rayB[i];
+            V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
+            sid = f2u(b.z);
+            node = f2u(b.w);
+            uint32_t prim;
+            if (FUSED) { float t; prim = nearest_hit(sc, o, d, t); }
+            else prim = L.hitprim[i];
+            uint32_t nkey = rng_node_key(sample_key_of(sc, pp, sid), node);
+            shade_hit(sc, o, d, prim, nkey, out);
+            if (out.kind == NK_LEAF) {
+                if (level == 0) {
+                    L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
+                } else {
+                    uint32_t par = L.parent[i];
+                    float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
+                    if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+                }
+            } else {
+                L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.coef_w);
+            }
+            L.meta[i] = out.kind;
+        }
+        bool has0 = valid && out.n_children >= 1, has1 = valid && out.n_children >= 2;
+        uint32_t i0, i1;
+        wave_append(Lnext, shard, has0, has1, i0, i1, ctr);
+        if (has0) {
+            Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
+            Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(sid), u2f(2u * node));
+            Lnext.parent[i0] = (i << 1);
+        }
+        if (has1) {
+            Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
+            Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(sid), u2f(2u * node + 1u));
+            Lnext.parent[i1] = (i << 1) | 1u;
+        }
+    }
+}
+
+// ---- terminal level (depth == 0): reference src/tracer.rs:451-492 ------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, PassParams pp, Counters *ctr) {
+    TileMap m = tile_map(L);
+    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
+        uint32_t i;
+        bool valid = tile_record(m, L, w, i);
+        bool shadow = false;
+        if (valid) {
+            float4 a = L.rayA[i], b = L.rayB[i];
+            V3 o = v3(a.x, a.y, a.z);
+            uint32_t nkey = rng_node_key(sample_key_of(sc, pp, f2u(b.z)), f2u(b.w));
+            V3 value = v3(0.0f, 0.0f, 0.0f), dir, radiance;
+            float dist;
+            shadow = terminal_sample(sc, o, nkey, dir, dist, radiance);
+            if (shadow) {
+                float t;
+                uint32_t prim = nearest_hit(sc, o, dir, t);
+                if (prim != MISS && t > dist - 0.000001f) value = radiance;
+            }
+            uint32_t par = L.parent[i];
+            float4 v = make_float4(value.x, value.y, value.z, 0.0f);
+            if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+        }
+        unsigned long long sm = __ballot(shadow);
+        if (sm != 0 && lane_id() == 0) atomicAdd(&ctr->rays, (unsigned long long)__popcll(sm));
+    }
+}
+
+// ---- backward sweep: inner nodes of level l >= 1 hand their radiance to their parents ------------------------------
+__global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
+    TileMap m = tile_map(L);
+    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
+        uint32_t i;
+        if (!tile_record(m, L, w, i)) continue;
+        uint32_t kind = L.meta[i];
+        if (kind == NK_LEAF) continue;
+        float4 c = L.coef[i], a = L.val0[i];
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kind == NK_GLASS) b = L.val1[i];
+        V3 value = node_value(kind, v3(c.x, c.y, c.z), c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+        uint32_t par = L.parent[i];
+        float4 v = make_float4(value.x, value.y, value.z, 0.0f);
+        if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+    }
+}
+
+// ---- resolve: reference src/tracer.rs:634-643 (tone map, gamma, Pixel32::from_unit, add_pixel32) --------------------------
+// u32 adds are exact and order independent, so atomics keep the result deterministic when a pass holds
+// several samples of one pixel.
+__global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassParams pp, uint32_t n_records, uint32_t *pixels32) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_records; i += gridDim.x * BLOCK) {
+        uint32_t kind = L0.meta[i];
+        float4 c = L0.coef[i];
+        V3 value = v3(c.x, c.y, c.z);
+        if (kind != NK_LEAF) {
+            float4 a = L0.val0[i];
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kind == NK_GLASS) b = L0.val1[i];
+            value = node_value(kind, value, c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+        }
+        uint32_t q[3];
+        tonemap_gamma_quantise(sc, value, q);
+        uint32_t pixel = i % pp.n_pixels;
+        atomicAdd(&pixels32[3 * pixel + 0], q[0]);
+        atomicAdd(&pixels32[3 * pixel + 1], q[1]);
+        atomicAdd(&pixels32[3 * pixel + 2], q[2]);
+    }
+}
+
+// ---- bookkeeping -----------------------------------------------------------------------------------------------
+// Adds this pass's record/ray counts to the running totals: rays = records of the traced levels 0..D-1
+// (shadow rays are added by k_terminal).
+__global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, Counters *ctr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long rec = 0, rays = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        unsigned long long n = 0;
+        for (int q = 0; q < NSHARD; ++q) {
+            uint32_t c = counts[l * NSHARD + q];
+            n += c < shard_caps[l] ? c : shard_caps[l];
+        }
+        rec += n;
+        if (l < n_levels - 1) rays += n;
+    }
+    ctr->records += rec;
+    ctr->rays += rays;
+}
+
+// Backbuffer.pixels8: reference src/tracer.rs:271-282
+__global__ __launch_bounds__(BLOCK) void k_pixels8(const uint32_t *pixels32, uint8_t *pixels8, uint32_t n_words, float iso_factor,
+                                                  uint32_t num_samples) {
+    float n = (float)num_samples;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += gridDim.x * BLOCK) {
+        float v = num_samples ? min_rs(255.0f, iso_factor * (float)pixels32[i] / n) : 0.0f;
+        pixels8[i] = (uint8_t)f32_as_u8(v);
+    }
+}
+
+// Parity hook: primary-hit primitive ids for one sample index.
+__global__ __launch_bounds__(BLOCK) void k_primary_ids(DevScene sc, uint32_t sample_index, uint32_t *ids) {
+    uint32_t n = sc.width * sc.height;
+    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < n; pixel += gridDim.x * BLOCK) {
+        uint32_t skey = rng_sample_key(sc.seed, pixel, sample_index);
+        V3 o, d;
+        pinhole_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
+        float t;
+        ids[pixel] = nearest_hit(sc, o, d, t);
+    }
+}
+
+// Test hook: the deterministic math functions as the kernels evaluate them.
+__global__ void k_eval_math(int fn, const float *a, const float *b, float *out, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        float x = a[i], y = b ? b[i] : 0.0f, r;
+        switch (fn) {
+        case 0: r = det::sinf_(x); break;
+        case 1: r = det::cosf_(x); break;
+        case 2: r = det::powf_(x, y); break;
+        case 3: r = det::expf_(x); break;
+        case 4: r = det::acosf_(x); break;
+        default: r = det::atan2f_(x, y); break;
+        }
+        out[i] = r;
+    }
+}
+
+}  // namespace pt

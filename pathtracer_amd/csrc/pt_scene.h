@@ -1,0 +1,406 @@
+// pt_scene.h -- flattened scene as the kernels see it, ray/primitive intersection and surface shading.
+//
+// Follows the reference function by function (paths relative to the reference checkout):
+//   src/scene.rs:169-221   intersect_sphere          -> sphere_test / sphere_hit
+//   src/scene.rs:223-261   intersect_plane           -> plane_test / plane_hit
+//   src/scene.rs:263-297   find_scene_hit            -> nearest_brute (linear scan) / pt_bvh.h (BVH)
+//   src/tracer.rs:285-446  reflect, refract, bases, BRDFs, samplers
+//   src/tracer.rs:448-584  trace_radiance            -> shade_hit (one call level, children returned instead
+//                                                       of recursed into) + node_value (the combine step)
+//   src/tracer.rs:586-616  tone mapping, gamma       -> tonemap_gamma
+// All arithmetic keeps the reference's evaluation order (see pt_math.h for the vector-op definitions).
+#pragma once
+
+#include "pt_math.h"
+
+namespace pt {
+
+constexpr uint32_t MISS = 0xFFFFFFFFu;
+
+// Material kinds, reference src/scene.rs:84-92
+enum : uint32_t { MAT_NONE = 0, MAT_EMISSIVE = 1, MAT_MIRROR = 2, MAT_TRANSLUCENT = 3, MAT_PHYSICALLY = 4 };
+enum : int { TONE_CLAMP = 0, TONE_REINHARD = 1, TONE_EXPOSURE = 2 };
+enum : int { SKY_CONSTANT = 0, SKY_HDRI = 1 };
+
+struct BvhNode;  // pt_bvh.h
+
+// Device view of a Scene (reference src/scene.rs:151-160) after host-side flattening.  Primitive ids run
+// over spheres, emissive spheres, planes, emissive planes in that order (src/scene.rs:266,280).
+struct DevScene {
+    uint32_t n_sph;          // spheres + emissive spheres
+    uint32_t n_pl;           // planes + emissive planes
+    uint32_t n_es, n_ep;     // emissive spheres / emissive planes (the lights of tracer.rs:453)
+    uint32_t n_pl_plain;     // non-emissive planes: emissive plane k has plane slot n_pl_plain + k
+    const float4 *sph;       // [n_sph]      (origin.xyz, radius)
+    const float4 *pln;       // [n_pl * 4]   (n.xyz, s.x) (s.yz, un.xy) (un.z, |u|, vn.xy) (vn.z, |v|, 0, 0)
+    const float4 *mat;       // [(n_sph + n_pl) * 2]  (kind, color.xyz) (roughness, metalness, ior, 0)
+    const float4 *lights;    // [n_es] radiance of emissive spheres, then [n_ep * 4] emissive planes:
+                             //   (origin.xyz, n.x) (n.yz, u.xy) (u.z, v.xyz) (radiance.xyz, 0)
+    const BvhNode *bvh_nodes;   // null: linear scan
+    const uint32_t *bvh_prims;  // primitive ids referenced by BVH leaves, ascending inside a leaf
+    const uint32_t *bvh_always; // primitives that cannot be bounded: tested for every ray
+    uint32_t n_always;
+    // camera (reference src/tracer.rs:104-111: per-pixel step vectors of CameraSampler)
+    V3 cam_origin, cam_su, cam_sv, cam_pos;
+    int tone; float exposure; float iso_factor;
+    int sky_kind; V3 sky_radiance; const float *sky_pixels; uint32_t sky_w, sky_h;
+    uint32_t width, height;
+    int jitter;
+    uint32_t seed;
+    int max_depth;
+};
+
+struct Hit { float t; V3 position; V3 normal; int transition; };  // transition 0 = In, 1 = Out
+
+// ---- spheres: reference src/scene.rs:169-221 ---------------------------------------------------------
+// Accept/reject and distance only (what the nearest-hit search needs).
+PT_HD bool sphere_test(float4 sp, V3 p, V3 d, float &t) {
+    V3 s = v3(sp.x, sp.y, sp.z);
+    float r = sp.w;
+    V3 c = s - p;
+    float e_len = dot(d, c);
+    if (e_len < -r) return false;
+    V3 e = e_len * d;
+    V3 v = e - c;
+    float v_len = length(v);
+    if (v_len > r) return false;
+    float b = sqrt_ieee(r * r - v_len * v_len);
+    float t1 = e_len - b;
+    float t2 = e_len + b;
+    if (t1 >= 0.0f) { t = t1; return true; }
+    if (t2 >= 0.0f) { t = t2; return true; }
+    return false;
+}
+// Full hit record of a sphere already known to be hit.
+PT_HD bool sphere_hit(float4 sp, V3 p, V3 d, Hit &h) {
+    V3 s = v3(sp.x, sp.y, sp.z);
+    float r = sp.w;
+    V3 c = s - p;
+    float e_len = dot(d, c);
+    if (e_len < -r) return false;
+    V3 e = e_len * d;
+    V3 v = e - c;
+    float v_len = length(v);
+    if (v_len > r) return false;
+    float b = sqrt_ieee(r * r - v_len * v_len);
+    float t1 = e_len - b;
+    float t2 = e_len + b;
+    if (t1 >= 0.0f) {
+        h.t = t1; h.position = p + t1 * d; h.normal = normalize(h.position - s); h.transition = 0;
+        return true;
+    }
+    if (t2 >= 0.0f) {
+        h.t = t2; h.position = p + t2 * d; h.normal = normalize(s - h.position); h.transition = 1;
+        return true;
+    }
+    return false;
+}
+
+// ---- planes: reference src/scene.rs:223-261 ----------------------------------------------------------
+// The reference recomputes normalize(u), length(u), normalize(v), length(v) per ray; they depend on the
+// plane only, so the host stores them (same operations, same bits).  find_scene_hit keeps a plane hit only
+// when its transition is In (src/scene.rs:282), i.e. dot(d, n) < 0; dot(d, n) and `denum` are the same sum.
+PT_HD bool plane_test(float4 q0, float4 q1, float4 q2, float4 q3, V3 p, V3 d, float &t, V3 &position) {
+    V3 n = v3(q0.x, q0.y, q0.z);
+    V3 s = v3(q0.w, q1.x, q1.y);
+    float num = n.x * (s.x - p.x) + n.y * (s.y - p.y) + n.z * (s.z - p.z);
+    float denum = n.x * d.x + n.y * d.y + n.z * d.z;
+    if (__builtin_fabsf(denum) < 0.0000001f) return false;
+    float parameter = num / denum;
+    if (parameter < 0.0f) return false;
+    position = p + parameter * d;
+    V3 in_plane = position - s;
+    float on_u = dot(in_plane, v3(q1.z, q1.w, q2.x));
+    if (on_u > q2.y || on_u < 0.0f) return false;
+    float on_v = dot(in_plane, v3(q2.z, q2.w, q3.x));
+    if (on_v > q3.y || on_v < 0.0f) return false;
+    if (!(dot(d, n) < 0.0f)) return false;  // Transition::Out: discarded by find_scene_hit
+    t = parameter;
+    return true;
+}
+
+// ---- nearest hit by linear scan: reference src/scene.rs:263-297 ---------------------------------------
+// A later primitive replaces the current nearest only when strictly closer.
+PT_HD uint32_t nearest_brute(const float4 *sph, uint32_t n_sph, const float4 *pln, uint32_t n_pl, V3 p, V3 d, float &best_t) {
+    uint32_t best = MISS;
+    best_t = 0.0f;
+    for (uint32_t i = 0; i < n_sph; ++i) {
+        float t;
+        if (sphere_test(sph[i], p, d, t)) {
+            if (best == MISS || t < best_t) { best = i; best_t = t; }
+        }
+    }
+    for (uint32_t i = 0; i < n_pl; ++i) {
+        float t; V3 pos;
+        if (plane_test(pln[4 * i], pln[4 * i + 1], pln[4 * i + 2], pln[4 * i + 3], p, d, t, pos)) {
+            if (best == MISS || t < best_t) { best = n_sph + i; best_t = t; }
+        }
+    }
+    return best;
+}
+
+// Rebuild the full Hit of primitive `prim` for ray (p, d); `prim` must be what the nearest-hit search returned.
+PT_HD bool prim_hit(const DevScene &sc, uint32_t prim, V3 p, V3 d, Hit &h) {
+    if (prim < sc.n_sph) return sphere_hit(sc.sph[prim], p, d, h);
+    uint32_t k = prim - sc.n_sph;
+    float4 q0 = sc.pln[4 * k];
+    float t; V3 pos;
+    if (!plane_test(q0, sc.pln[4 * k + 1], sc.pln[4 * k + 2], sc.pln[4 * k + 3], p, d, t, pos)) return false;
+    h.t = t; h.position = pos; h.normal = v3(q0.x, q0.y, q0.z); h.transition = 0;
+    return true;
+}
+
+// ---- optics and BRDFs: reference src/tracer.rs:285-446 ------------------------------------------------
+PT_HD V3 reflect(V3 incoming, V3 normal) { return incoming - (2.0f * dot(incoming, normal)) * normal; }  // :285-288
+
+PT_HD V3 refract(V3 incoming, V3 normal, float n1, float n2) {  // :290-318
+    V3 v = -incoming;
+    float cos_theta1 = dot(v, normal);
+    float sin_theta1 = sqrt_ieee(1.0f - cos_theta1 * cos_theta1);
+    float sin_theta2 = (sin_theta1 * n1) / n2;
+    float cos_theta2 = sqrt_ieee(1.0f - sin_theta2 * sin_theta2);
+    V3 p = incoming + cos_theta1 * normal;
+    return (-normal) * cos_theta2 + normalize(p) * sin_theta2;
+}
+
+struct Basis { V3 x, y, z; };
+PT_HD Basis construct_coordinate_system(V3 normal) {  // :320-331 (x is NOT normalised)
+    const float EPS = 0.9999f;
+    V3 other = (normal.y > EPS || normal.y < -EPS) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f);
+    Basis b;
+    b.y = normal;
+    b.x = cross(b.y, other);
+    b.z = cross(b.y, b.x);
+    return b;
+}
+PT_HD V3 to_basis(const Basis &b, V3 v) { return (b.x * v.x + b.y * v.y) + b.z * v.z; }  // :443-446
+
+PT_HD float geometry_schlick_ggx(V3 n, V3 a, float k) {  // :382-387
+    float n_dot_a = max_rs(0.0f, dot(n, a));
+    float denom = n_dot_a * (1.0f - k) + k;
+    return n_dot_a / denom;
+}
+PT_HD V3 fresnel_schlick(float cos_theta, V3 f0) {  // :391-393
+    return f0 + (v3(1.0f, 1.0f, 1.0f) - f0) * det::powf_(1.0f - cos_theta, 5.0f);
+}
+PT_HD V3 brdf_cook_torrance(V3 v, V3 l, V3 n, float roughness, V3 f0) {  // :395-415
+    float alpha = roughness * roughness;
+    V3 h = normalize(v + l);
+    float cos_theta = max_rs(0.0f, dot(h, v));
+    float k = alpha / 2.0f;
+    float g = geometry_schlick_ggx(n, l, k) * geometry_schlick_ggx(n, v, k);  // :370-389
+    V3 num = fresnel_schlick(cos_theta, f0) * g;
+    float denum = 4.0f * max_rs(0.0f, dot(n, v));
+    return num / denum;
+}
+PT_HD V3 importance_sample_ggx(float xi_x, float xi_y, float roughness) {  // :419-430
+    float a = roughness * roughness;
+    float phi = 2.0f * PI_F * xi_x;
+    float sin_phi, cos_phi;
+    det::sincosf_(phi, sin_phi, cos_phi);
+    float cos_theta = sqrt_ieee((1.0f - xi_y) / (xi_y * (a * a - 1.0f) + 1.0f));
+    float sin_theta = sqrt_ieee(1.0f - cos_theta * cos_theta);
+    return v3(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
+}
+PT_HD V3 importance_sample_cos(float xi_x, float xi_y) {  // :433-441
+    float r = sqrt_ieee(xi_x);
+    float theta = 2.0f * PI_F * xi_y;
+    float s, c;
+    det::sincosf_(theta, s, c);
+    return v3(r * c, sqrt_ieee(max_rs(0.0f, 1.0f - xi_x)), r * s);
+}
+
+// ---- one level of trace_radiance: reference src/tracer.rs:494-583 --------------------------------------
+// The recursion `L = f(L_child...)` is split: shade_hit decides what kind of node this call is, returns the
+// coefficients of f and the child rays; node_value applies f once the children's radiance is known.
+enum : uint32_t { NK_LEAF = 0, NK_MIRROR = 1, NK_SPECULAR = 2, NK_DIFFUSE = 3, NK_GLASS = 4 };
+
+struct NodeOut {
+    uint32_t kind;
+    V3 coef;       // LEAF: the radiance; SPECULAR: PI*brdf; DIFFUSE: PI*lambert; GLASS: fresnel (k_refl)
+    float coef_w;  // DIFFUSE: light_cos_theta
+    int n_children;
+    V3 o0, d0;     // child 0: mirror / specular / diffuse bounce, or the glass REFRACTION ray (path node 2n)
+    V3 o1, d1;     // child 1: the glass REFLECTION ray (path node 2n+1)
+};
+
+PT_HD V3 sky_radiance(const DevScene &sc, V3 direction);
+
+PT_HD void shade_hit(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, uint32_t node_key, NodeOut &out) {
+    out.n_children = 0;
+    out.coef_w = 0.0f;
+    out.kind = NK_LEAF;
+    Hit hit;
+    if (prim == MISS || !prim_hit(sc, prim, origin, direction, hit)) {  // :571-583
+        out.coef = sky_radiance(sc, direction);
+        return;
+    }
+    const float SHIFT_AMOUNT = 0.0001f;  // :495
+    const float R = 0.04f;               // :499
+    float4 m0 = sc.mat[2 * prim], m1 = sc.mat[2 * prim + 1];
+    uint32_t kind = f2u(m0.x);
+    V3 color = v3(m0.y, m0.z, m0.w);
+    V3 outwards = hit.position + SHIFT_AMOUNT * hit.normal;
+    switch (kind) {
+    case MAT_NONE:  // :502
+        out.coef = v3(1.0f, 1.0f, 1.0f);
+        return;
+    case MAT_EMISSIVE:  // :503-505
+        out.coef = color;
+        return;
+    case MAT_MIRROR: {  // :506-510
+        out.kind = NK_MIRROR;
+        out.coef = v3(0.0f, 0.0f, 0.0f);
+        out.n_children = 1;
+        out.o0 = outwards;
+        out.d0 = normalize(reflect(direction, hit.normal));
+        return;
+    }
+    case MAT_TRANSLUCENT: {  // :511-536
+        float ior = m1.z;
+        float n1 = hit.transition == 0 ? 1.0f : ior;
+        float n2 = hit.transition == 0 ? ior : 1.0f;
+        out.kind = NK_GLASS;
+        out.n_children = 2;
+        out.o0 = hit.position - SHIFT_AMOUNT * hit.normal;
+        out.d0 = normalize(refract(direction, hit.normal, n1, n2));
+        out.o1 = outwards;
+        out.d1 = normalize(reflect(direction, hit.normal));
+        float cos_theta = max_rs(0.0f, dot(hit.normal, -direction));
+        out.coef = fresnel_schlick(cos_theta, v3(R, R, R));
+        return;
+    }
+    default: {  // MAT_PHYSICALLY, :537-569
+        float roughness = m1.x, metalness = m1.y;
+        Basis ts = construct_coordinate_system(hit.normal);
+        V3 view = -direction;
+        V3 f0 = (1.0f - metalness) * v3(R, R, R) + metalness * color;  // mix_vec3, src/common.rs:68-70
+        float xi_x = random32(rng_draw(node_key, 0));
+        float xi_y = random32(rng_draw(node_key, 1));
+        float a = random32(rng_draw(node_key, 2));
+        uint32_t ch = rng_draw(node_key, 3) % 3u;
+        float f0c = ch == 0 ? f0.x : (ch == 1 ? f0.y : f0.z);
+        out.n_children = 1;
+        out.o0 = outwards;
+        if (a < f0c) {
+            V3 h = to_basis(ts, importance_sample_ggx(xi_x, xi_y, roughness));
+            V3 light = reflect(direction, h);
+            out.d0 = normalize(light);
+            out.kind = NK_SPECULAR;
+            out.coef = PI_F * brdf_cook_torrance(view, light, hit.normal, roughness, f0);
+        } else {
+            V3 light = to_basis(ts, importance_sample_cos(xi_x, xi_y));
+            out.d0 = normalize(light);
+            out.kind = NK_DIFFUSE;
+            out.coef = PI_F * (color / PI_F);  // PI * brdf_lambert, :334-337,567
+            out.coef_w = dot(light, hit.normal);
+        }
+        return;
+    }
+    }
+}
+
+// Radiance of a node from its coefficients and its children's radiance (the tail of each match arm of
+// reference src/tracer.rs:501-569).
+PT_HD V3 node_value(uint32_t kind, V3 coef, float coef_w, V3 child0, V3 child1) {
+    switch (kind) {
+    case NK_LEAF: return coef;
+    case NK_MIRROR: return child0;                                  // :509
+    case NK_SPECULAR: return coef * child0;                         // :560  (PI*brdf) * L
+    case NK_DIFFUSE: return (coef * child0) * coef_w;               // :567  ((PI*lambert) * L) * cos
+    default: return coef * child1 + (v3(1.0f, 1.0f, 1.0f) - coef) * child0;  // :532-535 k_refl*l_refl + k_refr*l_refr
+    }
+}
+
+// ---- sky: reference src/tracer.rs:571-583, src/scene.rs:32-68 ------------------------------------------
+PT_HD float repeat_f32(float x) {
+    float t = (float)(int)x;
+    if (x < 0.0f) return x - t + 1.0f;
+    return x - t;
+}
+PT_HD V3 sky_radiance(const DevScene &sc, V3 direction) {
+    if (sc.sky_kind == SKY_CONSTANT) return sc.sky_radiance;
+    if (sc.sky_pixels == nullptr) return v3(1.0f, 1.0f, 1.0f);  // texture not loaded yet
+    float u = det::atan2f_(direction.z, direction.x) / (2.0f * PI_F);
+    float v = det::acosf_(direction.y) / PI_F;
+    u = repeat_f32(u);
+    v = repeat_f32(v);
+    float fx = u * (float)sc.sky_w, fy = v * (float)sc.sky_h;
+    uint64_t px = (fx > 0.0f) ? (uint64_t)fx : 0u;
+    uint64_t py = (fy > 0.0f) ? (uint64_t)fy : 0u;
+    uint64_t last = (uint64_t)sc.sky_w * sc.sky_h * 3u - 3u;
+    uint64_t index = 3u * (py * sc.sky_w + px);
+    if (index > last) index = last;
+    return v3(sc.sky_pixels[index], sc.sky_pixels[index + 1], sc.sky_pixels[index + 2]);
+}
+
+// ---- terminal light sample: reference src/tracer.rs:451-492, src/scene.rs:116-148 -----------------------
+// Returns true when a shadow ray has to be traced; `radiance` is what the node is worth if that ray reaches
+// the light (hit.t > light_distance - 1e-6).  Returns false when the node is black.
+PT_HD bool terminal_sample(const DevScene &sc, V3 origin, uint32_t node_key, V3 &shadow_dir, float &light_distance, V3 &radiance) {
+    uint32_t n_lights = sc.n_es + sc.n_ep;
+    if (n_lights == 0) return false;  // the reference panics (`% 0`); defined as black
+    uint32_t r = rng_draw(node_key, 0) % n_lights;
+    V3 sample_point;
+    if (r < sc.n_es) {  // Sphere::sample, src/scene.rs:136-148: unit sphere at the world origin
+        float4 rad = sc.lights[r];
+        radiance = v3(rad.x, rad.y, rad.z);
+        float r1 = random32(rng_draw(node_key, 1));
+        float r2 = random32(rng_draw(node_key, 2));
+        float theta = 2.0f * PI_F * r1;
+        float phi = det::acosf_(2.0f * r2 - 1.0f);
+        float st, ct, sp, cp;
+        det::sincosf_(theta, st, ct);
+        det::sincosf_(phi, sp, cp);
+        sample_point = v3(st * cp, ct, st * sp);
+    } else {
+        // src/tracer.rs:464 indexes emissive_planes[r] without subtracting the sphere count
+        if (r >= sc.n_ep) return false;  // out of range: the reference panics; defined as black
+        const float4 *L = sc.lights + sc.n_es + 4 * r;
+        float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+        V3 lo = v3(l0.x, l0.y, l0.z), ln = v3(l0.w, l1.x, l1.y);
+        V3 lu = v3(l1.z, l1.w, l2.x), lv = v3(l2.y, l2.z, l2.w);
+        radiance = v3(l3.x, l3.y, l3.z);
+        if (dot(lo - origin, ln) < 0.0f) return false;  // Plane::sample, src/scene.rs:117, before any draw
+        float r1 = random32(rng_draw(node_key, 1));
+        float r2 = random32(rng_draw(node_key, 2));
+        sample_point = (lo + r1 * lu) + r2 * lv;
+    }
+    V3 light_ray = sample_point - origin;
+    light_distance = length(light_ray);
+    shadow_dir = normalize(light_ray);
+    return true;
+}
+
+// ---- tone mapping + gamma + quantisation: reference src/tracer.rs:586-616,634-641, src/common.rs:44-57,78-82
+PT_HD float clampf32(float mn, float mx, float x) { if (x > mx) return mx; else if (x < mn) return mn; else return x; }
+PT_HD void tonemap_gamma_quantise(const DevScene &sc, V3 hdr, uint32_t q[3]) {
+    V3 ldr;
+    if (sc.tone == TONE_CLAMP) ldr = v3(clampf32(0.0f, 1.0f, hdr.x), clampf32(0.0f, 1.0f, hdr.y), clampf32(0.0f, 1.0f, hdr.z));
+    else if (sc.tone == TONE_REINHARD) ldr = hdr / (v3(1.0f, 1.0f, 1.0f) + hdr);
+    else {
+        float e = sc.exposure;
+        ldr = v3(1.0f - det::expf_(-e * hdr.x), 1.0f - det::expf_(-e * hdr.y), 1.0f - det::expf_(-e * hdr.z));
+    }
+    const float GAMMA = 1.0f / 2.2f;
+    q[0] = f32_as_u32(det::powf_(ldr.x, GAMMA) * 255.0f);
+    q[1] = f32_as_u32(det::powf_(ldr.y, GAMMA) * 255.0f);
+    q[2] = f32_as_u32(det::powf_(ldr.z, GAMMA) * 255.0f);
+}
+
+// ---- primary rays: reference src/tracer.rs:125-142 ------------------------------------------------------
+PT_HD void pinhole_ray(const DevScene &sc, uint32_t x, uint32_t y, uint32_t sample_key, V3 &origin, V3 &direction) {
+    float offset_u = (float)x;
+    float offset_v = (float)y;
+    if (sc.jitter) {
+        uint32_t cam_key = rng_node_key(sample_key, 0u);
+        offset_u += random32(rng_draw(cam_key, 0));
+        offset_v += random32(rng_draw(cam_key, 1));
+    }
+    V3 du = offset_u * sc.cam_su;
+    V3 dv = offset_v * sc.cam_sv;
+    origin = (sc.cam_origin + du) + dv;
+    direction = normalize(origin - sc.cam_pos);
+}
+
+}  // namespace pt

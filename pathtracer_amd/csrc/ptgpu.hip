@@ -1,0 +1,639 @@
+// ptgpu.hip -- host side of libptgpu: the C ABI of include/ptgpu.h, scene flattening, queue memory and
+// the per-pass launch sequence.  Replaces the reference's WorkerPool fan-out and Backbuffer
+// (reference src/window.rs:104-116,166-196; src/tracer.rs:200-283).  No CPU rendering path exists here.
+#include "../../include/ptgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_kernels.h"
+#include "pt_bvh_build.h"
+
+using namespace pt;
+
+namespace {
+
+struct EventSpan { int kernel; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct PtHandle {
+    PtConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    bool have_scene = false;
+    DevScene sc{};
+    // device scene buffers
+    float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
+    float *d_sky = nullptr;
+    BvhNode *d_bvh_nodes = nullptr;
+    uint32_t *d_bvh_prims = nullptr, *d_bvh_always = nullptr;
+    uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
+    bool has_glass = false;
+
+    // accumulators
+    uint32_t *d_pixels32 = nullptr;
+    uint8_t *d_pixels8 = nullptr;
+    uint32_t *d_ids = nullptr;
+    uint64_t num_samples = 0;      // what pixels8 divides by (global count after a multi-GPU combine)
+    uint64_t local_samples = 0;    // samples per pixel this handle rendered since clear
+
+    // queues
+    int n_levels = 0;              // max_depth + 1
+    uint32_t batch = 0;            // samples per pixel per pass
+    std::vector<Level> levels;
+    std::vector<void *> level_allocs;
+    uint32_t *d_counts = nullptr;      // [n_levels * NSHARD]
+    uint32_t *d_shard_caps = nullptr;  // [n_levels]
+    Counters *d_ctr = nullptr;
+    bool fused = true;
+    size_t lds_bytes = 0;
+    uint64_t device_bytes = 0;
+
+    // profiling
+    std::vector<EventSpan> spans;
+    std::vector<hipEvent_t> free_events;
+    uint64_t kernel_launches[PT_KERNEL_COUNT] = {};
+    double kernel_ms[PT_KERNEL_COUNT] = {};
+};
+
+namespace {
+
+int fail(PtHandle *h, int code, const std::string &msg) {
+    if (h) h->error = msg;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(h, e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP,                    \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                  \
+    } while (0)
+
+template <class T>
+int dev_alloc(PtHandle *h, T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) return PT_OK;
+    HIPCHK(h, hipMalloc((void **)p, n * sizeof(T)));
+    h->device_bytes += n * sizeof(T);
+    return PT_OK;
+}
+
+template <class T>
+void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_scene(PtHandle *h) {
+    dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky);
+    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_prims); dev_free(h->d_bvh_always);
+    dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
+    for (void *p : h->level_allocs) (void)hipFree(p);
+    h->level_allocs.clear();
+    h->levels.clear();
+    dev_free(h->d_counts); dev_free(h->d_shard_caps); dev_free(h->d_ctr);
+    h->have_scene = false;
+    h->device_bytes = 0;
+}
+
+inline V3 toV3(PtVec3 v) { return v3(v.x, v.y, v.z); }
+
+float4 mat0(const PtMaterial &m) { return make_float4(u2f((uint32_t)m.kind), m.color.x, m.color.y, m.color.z); }
+float4 mat1(const PtMaterial &m) { return make_float4(m.roughness, m.metalness, m.ior, 0.0f); }
+
+// Per-plane constants of intersect_plane (reference src/scene.rs:244-249), computed once with the same operations.
+void pack_plane(const PtPlane &p, float4 *out) {
+    V3 u = toV3(p.u), v = toV3(p.v);
+    V3 un = normalize(u), vn = normalize(v);
+    float ul = length(u), vl = length(v);
+    out[0] = make_float4(p.normal.x, p.normal.y, p.normal.z, p.origin.x);
+    out[1] = make_float4(p.origin.y, p.origin.z, un.x, un.y);
+    out[2] = make_float4(un.z, ul, vn.x, vn.y);
+    out[3] = make_float4(vn.z, vl, 0.0f, 0.0f);
+}
+
+hipEvent_t get_event(PtHandle *h) {
+    if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Span {
+    PtHandle *h; int k; hipEvent_t a = nullptr, b = nullptr;
+    Span(PtHandle *h_, int k_) : h(h_), k(k_) {
+        if (h->cfg.profile_events) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+    }
+    ~Span() {
+        if (h->cfg.profile_events) { (void)hipEventRecord(b, h->stream); h->spans.push_back({k, a, b}); }
+    }
+};
+
+int drain_spans(PtHandle *h) {
+    for (auto &s : h->spans) {
+        float ms = 0.0f;
+        HIPCHK(h, hipEventSynchronize(s.stop));
+        HIPCHK(h, hipEventElapsedTime(&ms, s.start, s.stop));
+        h->kernel_ms[s.kernel] += ms;
+        h->kernel_launches[s.kernel] += 1;
+        h->free_events.push_back(s.start);
+        h->free_events.push_back(s.stop);
+    }
+    h->spans.clear();
+    return PT_OK;
+}
+
+__global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t shard_cap) {
+    uint32_t q = threadIdx.x;
+    uint64_t start = (uint64_t)q * shard_cap;
+    uint32_t c = 0;
+    if (start < n_records) c = (uint32_t)std::min<uint64_t>(shard_cap, n_records - start);
+    count0[q] = c;
+}
+
+uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
+
+int alloc_levels(PtHandle *h) {
+    const uint32_t P = h->sc.width * h->sc.height;
+    const int D = h->cfg.max_depth;
+    h->n_levels = D + 1;
+    uint32_t branch_cap = h->cfg.branch_capacity ? h->cfg.branch_capacity : 16u;
+    // samples per pixel per pass: about 4M records at level 0, bounded by a memory budget
+    uint32_t b = h->cfg.samples_per_batch;
+    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (4u << 20) / std::max<uint32_t>(P, 1)));
+    auto factor = [&](int l) -> uint64_t {
+        if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
+        return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
+    };
+    const uint64_t rec_bytes = 16 + 16 + 4 + 4 + 4 + 16 + 16 + 16;
+    const uint64_t budget = 24ull << 30;
+    for (;;) {
+        uint64_t total = 0;
+        for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4;
+        if (total <= budget || b == 1 || h->cfg.samples_per_batch != 0) break;
+        b = std::max<uint32_t>(1, b / 2);
+    }
+    h->batch = b;
+    const uint64_t S = (uint64_t)P * b;
+    std::vector<uint32_t> caps(h->n_levels);
+    h->levels.resize(h->n_levels);
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_counts, (size_t)h->n_levels * NSHARD))) return rc;
+    if ((rc = dev_alloc(h, &h->d_shard_caps, (size_t)h->n_levels))) return rc;
+    if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
+    for (int l = 0; l <= D; ++l) {
+        uint64_t recs = S * factor(l);
+        uint64_t per = (recs + NSHARD - 1) / NSHARD;
+        uint32_t cap = (l == 0) ? round_up(per, 64) : round_up(per + per / 4 + 128, 64);
+        if ((uint64_t)cap * NSHARD >= (1ull << 31))
+            return fail(h, PT_ERR_INVALID_ARGUMENT, "queue level too large for 31-bit record indices; lower samples_per_batch");
+        caps[l] = cap;
+        size_t n = (size_t)cap * NSHARD;
+        Level &L = h->levels[l];
+        L.shard_cap = cap;
+        L.count = h->d_counts + (size_t)l * NSHARD;
+        // one allocation per level, carved into the SoA arrays (16-byte arrays first)
+        size_t bytes = n * rec_bytes;
+        char *base = nullptr;
+        HIPCHK(h, hipMalloc((void **)&base, bytes));
+        h->device_bytes += bytes;
+        h->level_allocs.push_back(base);
+        L.rayA = (float4 *)base; base += n * 16;
+        L.rayB = (float4 *)base; base += n * 16;
+        L.coef = (float4 *)base; base += n * 16;
+        L.val0 = (float4 *)base; base += n * 16;
+        L.val1 = (float4 *)base; base += n * 16;
+        L.parent = (uint32_t *)base; base += n * 4;
+        L.hitprim = (uint32_t *)base; base += n * 4;
+        L.meta = (uint32_t *)base;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_shard_caps, caps.data(), caps.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, (size_t)h->n_levels * NSHARD * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+constexpr int GRID_TILES = 2048;  // persistent blocks of the tile kernels: 256 CUs x 8
+
+int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
+    const uint32_t P = h->sc.width * h->sc.height;
+    const uint32_t S = P * spp;
+    const int D = h->cfg.max_depth;
+    PassParams pp;
+    pp.n_pixels = P;
+    pp.sample_stride = h->cfg.shard_count;
+    pp.sample_first = h->cfg.shard_index + local_first * h->cfg.shard_count;
+    hipStream_t st = h->stream;
+    const uint32_t flat_grid = (uint32_t)std::min<uint64_t>(8192, (S + BLOCK - 1) / BLOCK);
+    const size_t lds = h->lds_bytes;
+
+    HIPCHK(h, hipMemsetAsync(h->d_counts + NSHARD, 0, (size_t)D * NSHARD * 4, st));
+    k_set_counts0<<<1, NSHARD, 0, st>>>(h->levels[0].count, S, h->levels[0].shard_cap);
+    {
+        Span s(h, PT_KERNEL_RAYGEN);
+        k_raygen<<<flat_grid, BLOCK, 0, st>>>(h->sc, h->levels[0], pp, S);
+    }
+    for (int l = 0; l < D; ++l) {
+        Level &L = h->levels[l];
+        Level &Lp = h->levels[l > 0 ? l - 1 : 0];
+        Level &Ln = h->levels[l + 1];
+        if (h->fused) {
+            Span s(h, PT_KERNEL_TRACE_SHADE);
+            k_shade<true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, h->d_ctr);
+        } else {
+            {
+                Span s(h, PT_KERNEL_TRACE);
+                k_trace<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L);
+            }
+            Span s(h, PT_KERNEL_SHADE);
+            k_shade<false><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, h->d_ctr);
+        }
+    }
+    {
+        Span s(h, PT_KERNEL_TERMINAL);
+        k_terminal<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, h->levels[D], h->levels[D - 1], pp, h->d_ctr);
+    }
+    for (int l = D - 1; l >= 1; --l) {
+        Span s(h, PT_KERNEL_GATHER);
+        k_gather<<<GRID_TILES, BLOCK, 0, st>>>(h->levels[l], h->levels[l - 1]);
+    }
+    {
+        Span s(h, PT_KERNEL_RESOLVE);
+        k_resolve<<<flat_grid, BLOCK, 0, st>>>(h->sc, h->levels[0], pp, S, h->d_pixels32);
+    }
+    k_account<<<1, 64, 0, st>>>(h->d_counts, h->d_shard_caps, h->n_levels, h->d_ctr);
+    HIPCHK(h, hipGetLastError());
+    return PT_OK;
+}
+
+int check_overflow(PtHandle *h) {
+    Counters c;
+    HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (c.overflow)
+        return fail(h, PT_ERR_QUEUE_OVERFLOW,
+                    "a ray queue level overflowed (glass branching beyond branch_capacity); accumulators are incomplete");
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ptgpu_default_config(PtConfig *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->device = 0;
+    cfg->seed = 314159265u;  // the reference's xorshift seed (src/common.rs:28), reused as the counter-RNG key
+    cfg->max_depth = 4;      // src/tracer.rs:633
+    cfg->sub_pixel_override = -1;
+    cfg->shard_index = 0;
+    cfg->shard_count = 1;
+    cfg->samples_per_batch = 0;
+    cfg->branch_capacity = 0;
+    cfg->accel = PT_ACCEL_AUTO;
+    cfg->fuse_trace_shade = -1;
+    cfg->profile_events = 0;
+}
+
+int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
+    if (!cfg || !out) return PT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (cfg->max_depth < 1 || cfg->max_depth > 24 || cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count)
+        return PT_ERR_INVALID_ARGUMENT;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || cfg->device < 0 || cfg->device >= n_dev) return PT_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return PT_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PT_ERR_NO_DEVICE;  // the kernels are built for gfx950 only
+    if (hipSetDevice(cfg->device) != hipSuccess) return PT_ERR_HIP;
+    PtHandle *h = new (std::nothrow) PtHandle();
+    if (!h) return PT_ERR_OUT_OF_MEMORY;
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PT_ERR_HIP; }
+    *out = h;
+    return PT_OK;
+}
+
+void ptgpu_destroy(PtHandle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_scene(h);
+    for (auto &s : h->spans) { (void)hipEventDestroy(s.start); (void)hipEventDestroy(s.stop); }
+    for (auto e : h->free_events) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
+    if (!h || !s) return PT_ERR_INVALID_ARGUMENT;
+    if (s->width == 0 || s->height == 0 || (uint64_t)s->width * s->height > (1ull << 28))
+        return fail(h, PT_ERR_INVALID_ARGUMENT, "image size must be 1..2^28 pixels");
+    if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_emissive_spheres && !s->emissive_spheres) ||
+        (s->n_emissive_planes && !s->emissive_planes))
+        return fail(h, PT_ERR_INVALID_ARGUMENT, "null primitive array with non-zero count");
+    const uint64_t n_sph = s->n_spheres + s->n_emissive_spheres, n_pl = s->n_planes + s->n_emissive_planes;
+    if (n_sph + n_pl >= (1ull << 28)) return fail(h, PT_ERR_INVALID_ARGUMENT, "too many primitives");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    free_scene(h);
+
+    // ---- flatten (ids: spheres, emissive spheres, planes, emissive planes; reference src/scene.rs:266,280)
+    std::vector<float4> sph(n_sph), pln(4 * n_pl), mat(2 * (n_sph + n_pl)), lights(s->n_emissive_spheres + 4 * s->n_emissive_planes);
+    bool glass = false;
+    size_t id = 0;
+    auto put_sphere = [&](const PtSphere &sp) {
+        sph[id] = make_float4(sp.origin.x, sp.origin.y, sp.origin.z, sp.radius);
+        mat[2 * id] = mat0(sp.material); mat[2 * id + 1] = mat1(sp.material);
+        glass |= sp.material.kind == PT_MAT_TRANSLUCENT;
+        ++id;
+    };
+    for (uint64_t i = 0; i < s->n_spheres; ++i) put_sphere(s->spheres[i]);
+    for (uint64_t i = 0; i < s->n_emissive_spheres; ++i) {
+        const PtMaterial &m = s->emissive_spheres[i].material;
+        lights[i] = make_float4(m.color.x, m.color.y, m.color.z, 0.0f);
+        put_sphere(s->emissive_spheres[i]);
+    }
+    auto put_plane = [&](const PtPlane &p) {
+        pack_plane(p, &pln[4 * (id - n_sph)]);
+        mat[2 * id] = mat0(p.material); mat[2 * id + 1] = mat1(p.material);
+        glass |= p.material.kind == PT_MAT_TRANSLUCENT;
+        ++id;
+    };
+    for (uint64_t i = 0; i < s->n_planes; ++i) put_plane(s->planes[i]);
+    for (uint64_t i = 0; i < s->n_emissive_planes; ++i) {
+        const PtPlane &p = s->emissive_planes[i];
+        float4 *L = &lights[s->n_emissive_spheres + 4 * i];
+        L[0] = make_float4(p.origin.x, p.origin.y, p.origin.z, p.normal.x);
+        L[1] = make_float4(p.normal.y, p.normal.z, p.u.x, p.u.y);
+        L[2] = make_float4(p.u.z, p.v.x, p.v.y, p.v.z);
+        L[3] = make_float4(p.material.color.x, p.material.color.y, p.material.color.z, 0.0f);
+        put_plane(p);
+    }
+    h->has_glass = glass;
+
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_sph, std::max<size_t>(1, sph.size())))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pln, std::max<size_t>(1, pln.size())))) return rc;
+    if ((rc = dev_alloc(h, &h->d_mat, std::max<size_t>(1, mat.size())))) return rc;
+    if ((rc = dev_alloc(h, &h->d_lights, std::max<size_t>(1, lights.size())))) return rc;
+    if (!sph.empty()) HIPCHK(h, hipMemcpy(h->d_sph, sph.data(), sph.size() * 16, hipMemcpyHostToDevice));
+    if (!pln.empty()) HIPCHK(h, hipMemcpy(h->d_pln, pln.data(), pln.size() * 16, hipMemcpyHostToDevice));
+    if (!mat.empty()) HIPCHK(h, hipMemcpy(h->d_mat, mat.data(), mat.size() * 16, hipMemcpyHostToDevice));
+    if (!lights.empty()) HIPCHK(h, hipMemcpy(h->d_lights, lights.data(), lights.size() * 16, hipMemcpyHostToDevice));
+
+    DevScene &sc = h->sc;
+    std::memset(&sc, 0, sizeof sc);
+    sc.n_sph = (uint32_t)n_sph; sc.n_pl = (uint32_t)n_pl;
+    sc.n_es = (uint32_t)s->n_emissive_spheres; sc.n_ep = (uint32_t)s->n_emissive_planes;
+    sc.n_pl_plain = (uint32_t)s->n_planes;
+    sc.sph = h->d_sph; sc.pln = h->d_pln; sc.mat = h->d_mat; sc.lights = h->d_lights;
+    // CameraSampler step vectors, reference src/tracer.rs:104-111
+    sc.cam_origin = toV3(s->camera.plane_origin);
+    sc.cam_su = toV3(s->camera.plane_u) / (float)s->width;
+    sc.cam_sv = toV3(s->camera.plane_v) / (float)s->height;
+    sc.cam_pos = toV3(s->camera.position);
+    sc.tone = s->camera.tone_mapping;
+    sc.exposure = s->camera.exposure;
+    sc.iso_factor = s->camera.iso / 100.0f;  // src/tracer.rs:621
+    sc.sky_kind = s->sky.kind;
+    sc.sky_radiance = toV3(s->sky.radiance);
+    sc.sky_pixels = nullptr;
+    if (s->sky.kind == PT_SKY_HDRI && s->sky.pixels && s->sky.width && s->sky.height) {
+        size_t n = (size_t)s->sky.width * s->sky.height * 3;
+        if ((rc = dev_alloc(h, &h->d_sky, n))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_sky, s->sky.pixels, n * 4, hipMemcpyHostToDevice));
+        sc.sky_pixels = h->d_sky;
+        sc.sky_w = (uint32_t)s->sky.width; sc.sky_h = (uint32_t)s->sky.height;
+    }
+    sc.width = s->width; sc.height = s->height;
+    sc.jitter = h->cfg.sub_pixel_override < 0 ? (s->sub_pixel_sampling != 0) : (h->cfg.sub_pixel_override != 0);
+    sc.seed = h->cfg.seed;
+    sc.max_depth = h->cfg.max_depth;
+
+    // ---- acceleration structure
+    bool want_bvh = h->cfg.accel == PT_ACCEL_BVH || (h->cfg.accel == PT_ACCEL_AUTO && n_sph + n_pl > 48);
+    h->bvh_nodes = h->bvh_leaf_prims = 0;
+    h->lds_bytes = 0;
+    if (want_bvh && n_sph + n_pl > 0) {
+        BvhBuilder builder;
+        builder.build(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
+        if ((rc = dev_alloc(h, &h->d_bvh_nodes, builder.nodes.size()))) return rc;
+        if ((rc = dev_alloc(h, &h->d_bvh_prims, std::max<size_t>(1, builder.prims.size())))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_bvh_nodes, builder.nodes.data(), builder.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+        if (!builder.prims.empty())
+            HIPCHK(h, hipMemcpy(h->d_bvh_prims, builder.prims.data(), builder.prims.size() * 4, hipMemcpyHostToDevice));
+        if ((rc = dev_alloc(h, &h->d_bvh_always, std::max<size_t>(1, builder.always.size())))) return rc;
+        if (!builder.always.empty())
+            HIPCHK(h, hipMemcpy(h->d_bvh_always, builder.always.data(), builder.always.size() * 4, hipMemcpyHostToDevice));
+        sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims;
+        sc.bvh_always = h->d_bvh_always; sc.n_always = (uint32_t)builder.always.size();
+        h->bvh_nodes = builder.nodes.size(); h->bvh_leaf_prims = builder.prims.size();
+        h->lds_bytes = (size_t)BVH_STACK * BVH_STACK_STRIDE * 4;
+    }
+    h->fused = h->cfg.fuse_trace_shade != 0;
+
+    // ---- accumulators and queues
+    const size_t P = (size_t)s->width * s->height;
+    if ((rc = dev_alloc(h, &h->d_pixels32, P * 3))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pixels8, P * 3))) return rc;
+    if ((rc = dev_alloc(h, &h->d_ids, P))) return rc;
+    if ((rc = alloc_levels(h))) return rc;
+    h->have_scene = true;
+    return ptgpu_clear(h);
+}
+
+int ptgpu_clear(PtHandle *h) {
+    if (!h) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t P = (size_t)h->sc.width * h->sc.height;
+    HIPCHK(h, hipMemsetAsync(h->d_pixels32, 0, P * 3 * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_pixels8, 0, P * 3, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc = drain_spans(h);
+    if (rc) return rc;
+    h->num_samples = 0;
+    h->local_samples = 0;
+    std::memset(h->kernel_launches, 0, sizeof h->kernel_launches);
+    std::memset(h->kernel_ms, 0, sizeof h->kernel_ms);
+    return PT_OK;
+}
+
+int ptgpu_render(PtHandle *h, uint32_t n_samples) {
+    if (!h) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint32_t done = 0;
+    while (done < n_samples) {
+        uint32_t spp = std::min(h->batch, n_samples - done);
+        int rc = run_pass(h, spp, (uint32_t)h->local_samples);
+        if (rc) return rc;
+        done += spp;
+        h->local_samples += spp;
+        h->num_samples += spp;
+        if (h->cfg.profile_events && h->spans.size() > 4096) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if ((rc = drain_spans(h))) return rc;
+        }
+    }
+    return PT_OK;
+}
+
+int ptgpu_sync(PtHandle *h) {
+    if (!h) return PT_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc = drain_spans(h);
+    if (rc) return rc;
+    if (h->have_scene) return check_overflow(h);
+    return PT_OK;
+}
+
+int ptgpu_read_pixels32(PtHandle *h, uint32_t *out, uint64_t *num_samples) {
+    if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    int rc = ptgpu_sync(h);
+    if (rc) return rc;
+    const size_t P = (size_t)h->sc.width * h->sc.height;
+    HIPCHK(h, hipMemcpy(out, h->d_pixels32, P * 3 * 4, hipMemcpyDeviceToHost));
+    if (num_samples) *num_samples = h->num_samples;
+    return PT_OK;
+}
+
+int ptgpu_read_pixels8(PtHandle *h, uint8_t *out) {
+    if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    int rc = ptgpu_sync(h);
+    if (rc) return rc;
+    const uint32_t n = h->sc.width * h->sc.height * 3;
+    k_pixels8<<<std::min<uint32_t>(4096, (n + BLOCK - 1) / BLOCK), BLOCK, 0, h->stream>>>(h->d_pixels32, h->d_pixels8, n, h->sc.iso_factor,
+                                                                                         (uint32_t)h->num_samples);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->d_pixels8, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out) {
+    if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint32_t n = h->sc.width * h->sc.height;
+    k_primary_ids<<<std::min<uint32_t>(8192, (n + BLOCK - 1) / BLOCK), BLOCK, h->lds_bytes, h->stream>>>(h->sc, sample_index, h->d_ids);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int ptgpu_device_pixels32(PtHandle *h, void **device_ptr, uint64_t *n_words) {
+    if (!h || !device_ptr) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    *device_ptr = h->d_pixels32;
+    if (n_words) *n_words = (uint64_t)h->sc.width * h->sc.height * 3;
+    return PT_OK;
+}
+
+int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples) {
+    if (!h) return PT_ERR_INVALID_ARGUMENT;
+    h->num_samples = num_samples;
+    return PT_OK;
+}
+
+int ptgpu_stream(PtHandle *h, void **stream) {
+    if (!h || !stream) return PT_ERR_INVALID_ARGUMENT;
+    *stream = (void *)h->stream;
+    return PT_OK;
+}
+
+int ptgpu_get_stats(PtHandle *h, PtStats *out) {
+    if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof *out);
+    if (h->have_scene) {
+        int rc = ptgpu_sync(h);
+        if (rc && rc != PT_ERR_QUEUE_OVERFLOW) return rc;
+        Counters c;
+        HIPCHK(h, hipMemcpy(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+        out->rays = c.rays;
+        out->records = c.records;
+        out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
+    }
+    out->bvh_nodes = h->bvh_nodes;
+    out->bvh_leaf_prims = h->bvh_leaf_prims;
+    for (int k = 0; k < PT_KERNEL_COUNT; ++k) { out->kernel_launches[k] = h->kernel_launches[k]; out->kernel_ms[k] = h->kernel_ms[k]; }
+    out->device_bytes = h->device_bytes;
+    return PT_OK;
+}
+
+const char *ptgpu_last_error(PtHandle *h) { return h ? h->error.c_str() : "null handle"; }
+
+// Camera::new + construct_projection_plane, reference src/tracer.rs:69-96
+void ptgpu_camera_new(PtVec3 position, PtVec3 target, PtVec3 up, float width, float height, float z_near, int32_t tone_mapping,
+                      float exposure, float iso, PtCamera *out) {
+    if (!out) return;
+    V3 pos = toV3(position);
+    V3 z = normalize(pos - toV3(target));
+    V3 x = normalize(cross(toV3(up), z));
+    V3 y = normalize(cross(z, x));
+    float half_width = width / 2.0f, half_height = height / 2.0f;
+    V3 to_plane_center = (-z_near) * z;
+    V3 origin = ((pos + to_plane_center) - x * half_width) - y * half_height;
+    V3 u = x * width, v = y * height;
+    out->plane_origin = {origin.x, origin.y, origin.z};
+    out->plane_u = {u.x, u.y, u.z};
+    out->plane_v = {v.x, v.y, v.z};
+    out->position = position;
+    out->width = width; out->height = height; out->z_near = z_near;
+    out->tone_mapping = tone_mapping; out->exposure = exposure; out->iso = iso;
+}
+
+// Plane::new, reference src/scene.rs:106
+void ptgpu_plane_normal(PtVec3 u, PtVec3 v, PtVec3 *out) {
+    if (!out) return;
+    V3 n = normalize(cross(toV3(u), toV3(v)));
+    *out = {n.x, n.y, n.z};
+}
+
+void ptgpu_plane_normals(PtPlane *planes, uint64_t n) {
+    if (!planes) return;
+    for (uint64_t i = 0; i < n; ++i) ptgpu_plane_normal(planes[i].u, planes[i].v, &planes[i].normal);
+}
+
+int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n) {
+    if (!h || !a || !out || fn < 0 || fn > 5) return PT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return PT_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(h, hipMalloc((void **)&da, n * 4));
+    HIPCHK(h, hipMalloc((void **)&dout, n * 4));
+    HIPCHK(h, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    if (b) {
+        HIPCHK(h, hipMalloc((void **)&db, n * 4));
+        HIPCHK(h, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    }
+    k_eval_math<<<(unsigned)std::min<uint64_t>(4096, (n + 255) / 256), 256, 0, h->stream>>>(fn, da, db, dout, n);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    if (e != hipSuccess) return fail(h, PT_ERR_HIP, hipGetErrorString(e));
+    return PT_OK;
+}
+
+}  // extern "C"
