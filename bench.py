@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the wavefront path tracer on the reference's sample scene at 1920x1080.
+
+One "step" = `--spp-per-step` samples per pixel over the whole 1080p image on every GPU (the reference's frame is
+1 spp: src/window.rs:166).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders
+its own sample-index shard and the u32 accumulators are summed once with RCCL inside the timed region.  Rank 0
+prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def cpu_baseline(sc, budget_s: float, threads: int):
+    """The reference's CPU path as restated in oracle/ (8-thread 32x32 tile pool, xorshift RNG, platform libm),
+    timed on a bounded number of 1-spp passes of the SAME workload."""
+    from oracle import ptref as R
+    osc = R.OracleScene(sc)
+    opt = R.options(R.RNG_XORSHIFT, R.MATH_LIBM)
+    import ctypes as C
+    import numpy as np
+    W, H = osc.width, osc.height
+    p32 = np.zeros((H, W, 3), dtype=np.uint32)
+    p8 = np.zeros((H, W, 3), dtype=np.uint8)
+    bb = R.Backbuffer(W, H, 1, p32.ctypes.data, p8.ctypes.data)
+    stats = R.Stats()
+    L = R.lib()
+    L.ptref_render_pass_pool(C.byref(osc.desc), C.byref(opt), C.byref(bb), threads, 0, C.byref(R.Stats()))  # warm-up pass
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        L.ptref_render_pass_pool(C.byref(osc.desc), C.byref(opt), C.byref(bb), threads, passes + 1, C.byref(stats))
+        bb.num_samples += 1
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or passes >= 64:
+            break
+    return {
+        "value": round(stats.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{passes} passes of 1 spp over the same {W}x{H} sample scene ({stats.rays} rays, {dt:.1f} s), "
+                  f"{threads}-thread 32x32 tile pool as src/window.rs:110,167",
+        "ms_per_pass": round(1e3 * dt / passes, 2),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-depth", type=int, default=4)
+    ap.add_argument("--fused", type=int, default=-1)
+    ap.add_argument("--batch", type=int, default=0, help="samples per pixel per pipeline pass (0 = library default)")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events (no roofline block)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import binding, distributed as D, scene as S
+
+    rank, world, local_rank = D.env_rank()
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    dev = torch.device("cuda", local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    sc = S.sample_scene(args.width, args.height, camera_width=5.0 * args.width / args.height)
+    gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, max_depth=args.max_depth,
+                        fuse_trace_shade=args.fused, samples_per_batch=args.batch, profile_events=0 if args.no_events else 1)
+    gpu.upload_scene(sc)
+    for _ in range(args.warmup):
+        gpu.render(args.spp_per_step)
+    gpu.sync()
+    if world > 1:
+        D.combine_accumulators(gpu, args.warmup * args.spp_per_step)  # warms RCCL up too
+    gpu.clear()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gpu.render(args.spp_per_step)
+    gpu.sync()
+    total_spp = D.combine_accumulators(gpu, args.steps * args.spp_per_step)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = gpu.stats()
+    agg = torch.tensor([float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays, samples, elapsed = float(agg[0].item()), float(agg[1].item()), float(tmax[0].item())
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s at 1080p on scenes/sample (ray = one nearest-hit query: primary + bounce + shadow)",
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"scenes/sample at {args.width}x{args.height} (camera.width {5.0 * args.width / args.height:.7f}), "
+                                   f"max_depth {args.max_depth}, {args.spp_per_step} spp per step per GPU",
+                       "spp_per_step": args.spp_per_step, "parallelism": f"sample-index shards x{world}",
+                       "accumulated_spp": total_spp},
+            "msamples_per_s": round(samples / elapsed / 1e6, 2),
+            "sec_to_1024_spp": round(1024.0 * args.width * args.height / (samples / elapsed), 3),
+            "rays_per_sample": round(rays / max(samples, 1.0), 3),
+        }
+        if not args.no_events:
+            # dominant kernel: the fused trace+shade launches (or trace, in the two-kernel pipeline)
+            kms, kl = st["kernel_ms"], st["kernel_launches"]
+            name = max(("trace_shade", "trace", "shade", "terminal", "gather", "resolve", "raygen"), key=lambda k: kms[k])
+            traced = st["rays"] - st["shadow_rays"]          # records of the traced levels
+            children = st["records"] - st["samples"]         # records appended to levels >= 1
+            if name == "trace_shade":
+                alg = 52.0 * traced + 36.0 * children         # read ray 32; write kind 4 + coef/val 16; write child 36
+            elif name == "trace":
+                alg = 36.0 * traced                           # read ray 32, write prim id 4
+            elif name == "shade":
+                alg = 56.0 * traced + 36.0 * children
+            else:
+                alg = 0.0
+            ms = kms[name]
+            n_launch = max(1, kl[name])
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(name)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "kernel": name,
+                "achieved": round(alg / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else 0.0,
+                "traffic": traffic,
+                "launches": int(kl[name]), "avg_launch_ms": round(ms / n_launch, 5),
+                "algorithmic_bytes_per_launch": round(alg / n_launch, 1),
+                "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_seconds, 8)
+        print(json.dumps(out), flush=True)
+
+    gpu.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

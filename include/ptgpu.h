@@ -114,6 +114,7 @@ enum { PT_KERNEL_RAYGEN = 0, PT_KERNEL_TRACE = 1, PT_KERNEL_SHADE = 2, PT_KERNEL
 typedef struct {
     uint64_t samples;                         /* pixel-samples accumulated by this handle since clear */
     uint64_t rays;                            /* nearest-hit queries (primary + bounce + shadow) since clear */
+    uint64_t shadow_rays;                     /* the part of `rays` traced by terminal light samples */
     uint64_t records;                         /* queue records processed over all levels since clear */
     uint64_t bvh_nodes, bvh_leaf_prims;       /* size of the current BVH (0 for brute force) */
     uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */
@@ -156,6 +157,10 @@ int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out);
  * host can all-reduce it in place (RCCL / torch.distributed), then set the global sample count. */
 int ptgpu_device_pixels32(PtHandle *h, void **device_ptr, uint64_t *n_words);
 int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples);
+/* The same combine for hosts that own the exchange buffer: copy the accumulator to / from device memory
+ * the caller provides (width*height*3 u32 words, on this handle's device). */
+int ptgpu_export_pixels32(PtHandle *h, void *dst_device);
+int ptgpu_import_pixels32(PtHandle *h, const void *src_device, uint64_t num_samples);
 /* The hipStream_t all work of this handle is enqueued on (as void*), for event timing by the caller. */
 int ptgpu_stream(PtHandle *h, void **stream);
 

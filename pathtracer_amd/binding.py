@@ -55,7 +55,7 @@ class PtConfig(C.Structure):
 
 
 class PtStats(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("records", C.c_uint64), ("bvh_nodes", C.c_uint64),
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("records", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_leaf_prims", C.c_uint64), ("kernel_launches", C.c_uint64 * PT_KERNEL_COUNT),
                 ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64)]
 
@@ -94,6 +94,8 @@ def load_library() -> C.CDLL:
     lib.ptgpu_device_pixels32.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.ptgpu_set_num_samples.argtypes = [H, C.c_uint64]
     lib.ptgpu_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.ptgpu_export_pixels32.argtypes = [H, C.c_void_p]
+    lib.ptgpu_import_pixels32.argtypes = [H, C.c_void_p, C.c_uint64]
     lib.ptgpu_get_stats.argtypes = [H, C.POINTER(PtStats)]
     lib.ptgpu_last_error.argtypes = [H]
     lib.ptgpu_last_error.restype = C.c_char_p
@@ -107,7 +109,7 @@ def load_library() -> C.CDLL:
     lib.ptgpu_eval_math.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     for name in ("ptgpu_create", "ptgpu_upload_scene", "ptgpu_clear", "ptgpu_render", "ptgpu_sync", "ptgpu_read_pixels32",
                  "ptgpu_read_pixels8", "ptgpu_render_primary_ids", "ptgpu_device_pixels32", "ptgpu_set_num_samples",
-                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math"):
+                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -237,6 +239,12 @@ class PtGpu:
     def set_num_samples(self, n: int) -> None:
         self._chk(self.lib.ptgpu_set_num_samples(self.h, int(n)))
 
+    def export_pixels32(self, dst_device_ptr: int) -> None:
+        self._chk(self.lib.ptgpu_export_pixels32(self.h, C.c_void_p(dst_device_ptr)))
+
+    def import_pixels32(self, src_device_ptr: int, num_samples: int) -> None:
+        self._chk(self.lib.ptgpu_import_pixels32(self.h, C.c_void_p(src_device_ptr), int(num_samples)))
+
     def stream(self) -> int:
         p = C.c_void_p()
         self._chk(self.lib.ptgpu_stream(self.h, C.byref(p)))
@@ -246,7 +254,7 @@ class PtGpu:
         st = PtStats()
         self._chk(self.lib.ptgpu_get_stats(self.h, C.byref(st)))
         return {
-            "samples": st.samples, "rays": st.rays, "records": st.records, "bvh_nodes": st.bvh_nodes,
+            "samples": st.samples, "rays": st.rays, "shadow_rays": st.shadow_rays, "records": st.records, "bvh_nodes": st.bvh_nodes,
             "bvh_leaf_prims": st.bvh_leaf_prims, "device_bytes": st.device_bytes,
             "kernel_launches": {KERNEL_NAMES[k]: st.kernel_launches[k] for k in range(PT_KERNEL_COUNT)},
             "kernel_ms": {KERNEL_NAMES[k]: st.kernel_ms[k] for k in range(PT_KERNEL_COUNT)},

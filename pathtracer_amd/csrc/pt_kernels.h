@@ -29,6 +29,8 @@
 namespace pt {
 
 constexpr int NSHARD = 64;
+constexpr int CSTRIDE = 32;  // u32 words between two shard counters: one 128-byte line each, because atomics on one
+                             // line serialise (~90/us) no matter which word of it they hit
 constexpr int BLOCK = 256;
 
 struct Level {
@@ -40,7 +42,7 @@ struct Level {
     float4 *coef;       // node coefficients (xyz, w)
     float4 *val0;       // radiance of child 0
     float4 *val1;       // radiance of child 1 (glass reflection)
-    uint32_t *count;    // [NSHARD] records per shard
+    uint32_t *count;    // [NSHARD * CSTRIDE] records per shard, shard q at count[q * CSTRIDE]
     uint32_t shard_cap;
 };
 
@@ -50,8 +52,8 @@ struct PassParams {
     uint32_t sample_stride;   // shard_count
 };
 
-// device-side counters (one allocation): [0] overflow flag, [1] pad, [2..3] rays (u64), [4..5] records (u64)
-struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays; unsigned long long records; };
+// device-side counters (one allocation)
+struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -61,7 +63,7 @@ struct TileMap { uint32_t cnt, incl, total; };  // per lane: records and inclusi
 __device__ __forceinline__ TileMap tile_map(const Level &L) {
     TileMap m;
     uint32_t lane = lane_id();
-    uint32_t c = L.count[lane];
+    uint32_t c = L.count[lane * CSTRIDE];
     m.cnt = c < L.shard_cap ? c : L.shard_cap;
     uint32_t incl = (m.cnt + 63u) >> 6;
 #pragma unroll
@@ -92,7 +94,7 @@ __device__ __forceinline__ void wave_append(const Level &L, uint32_t shard, bool
     i0 = i1 = 0;
     if (total == 0) return;
     uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(&L.count[shard], total);
+    if (lane_id() == 0) base = atomicAdd(&L.count[shard * CSTRIDE], total);
     base = __shfl(base, 0);
     if (base + total > L.shard_cap) {  // never drop silently: the host turns this into PT_ERR_QUEUE_OVERFLOW
         if (lane_id() == 0) atomicOr(&ctr->overflow, 1u);
@@ -114,9 +116,14 @@ __device__ __forceinline__ uint32_t sample_key_of(const DevScene &sc, const Pass
 }
 
 // ---- nearest hit (linear scan or BVH) -----------------------------------------------------------------
+// The linear scan reads the same primitive in every lane: through a constant-address-space pointer the
+// compiler issues s_load (scalar cache -> SGPRs) instead of 64 identical vector loads per fetch.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef const f4_t __attribute__((address_space(4))) *const_f4_ptr;
+
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t) {
     if (sc.bvh_nodes) return bvh_nearest(sc, o, d, t);
-    return nearest_brute(sc.sph, sc.n_sph, sc.pln, sc.n_pl, o, d, t);
+    return nearest_brute((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t);
 }
 
 // ---- raygen: reference src/tracer.rs:125-142,628-631 -------------------------------------------------------
@@ -198,8 +205,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, Level L, Level Lpr
 }
 
 // ---- terminal level (depth == 0): reference src/tracer.rs:451-492 ------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, PassParams pp, Counters *ctr) {
+// `shadow_count` is a row of per-shard counters like Level::count (zeroed every pass, summed by k_account).
+__global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, PassParams pp, uint32_t *shadow_count) {
     TileMap m = tile_map(L);
+    uint32_t n_shadow = 0;
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         bool valid = tile_record(m, L, w, i);
@@ -220,9 +229,9 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
             float4 v = make_float4(value.x, value.y, value.z, 0.0f);
             if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
         }
-        unsigned long long sm = __ballot(shadow);
-        if (sm != 0 && lane_id() == 0) atomicAdd(&ctr->rays, (unsigned long long)__popcll(sm));
+        n_shadow += (uint32_t)__popcll(__ballot(shadow));
     }
+    if (n_shadow != 0 && lane_id() == 0) atomicAdd(&shadow_count[my_shard() * CSTRIDE], n_shadow);
 }
 
 // ---- backward sweep: inner nodes of level l >= 1 hand their radiance to their parents ------------------------------
@@ -267,22 +276,25 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassPa
 }
 
 // ---- bookkeeping -----------------------------------------------------------------------------------------------
-// Adds this pass's record/ray counts to the running totals: rays = records of the traced levels 0..D-1
-// (shadow rays are added by k_terminal).
+// Adds this pass's record/ray counts to the running totals: rays = records of the traced levels 0..D-1;
+// row n_levels of `counts` holds the shadow rays counted by k_terminal.
 __global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, Counters *ctr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long rec = 0, rays = 0;
     for (int l = 0; l < n_levels; ++l) {
         unsigned long long n = 0;
         for (int q = 0; q < NSHARD; ++q) {
-            uint32_t c = counts[l * NSHARD + q];
+            uint32_t c = counts[(l * NSHARD + q) * CSTRIDE];
             n += c < shard_caps[l] ? c : shard_caps[l];
         }
         rec += n;
         if (l < n_levels - 1) rays += n;
     }
+    unsigned long long shadow = 0;
+    for (int q = 0; q < NSHARD; ++q) shadow += counts[(n_levels * NSHARD + q) * CSTRIDE];
     ctr->records += rec;
     ctr->rays += rays;
+    ctr->shadow += shadow;
 }
 
 // Backbuffer.pixels8: reference src/tracer.rs:271-282

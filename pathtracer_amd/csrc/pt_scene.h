@@ -54,7 +54,8 @@ struct Hit { float t; V3 position; V3 normal; int transition; };  // transition 
 
 // ---- spheres: reference src/scene.rs:169-221 ---------------------------------------------------------
 // Accept/reject and distance only (what the nearest-hit search needs).
-PT_HD bool sphere_test(float4 sp, V3 p, V3 d, float &t) {
+template <class T4>
+PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t) {
     V3 s = v3(sp.x, sp.y, sp.z);
     float r = sp.w;
     V3 c = s - p;
@@ -100,7 +101,8 @@ PT_HD bool sphere_hit(float4 sp, V3 p, V3 d, Hit &h) {
 // The reference recomputes normalize(u), length(u), normalize(v), length(v) per ray; they depend on the
 // plane only, so the host stores them (same operations, same bits).  find_scene_hit keeps a plane hit only
 // when its transition is In (src/scene.rs:282), i.e. dot(d, n) < 0; dot(d, n) and `denum` are the same sum.
-PT_HD bool plane_test(float4 q0, float4 q1, float4 q2, float4 q3, V3 p, V3 d, float &t, V3 &position) {
+template <class T4>
+PT_HD bool plane_test(T4 q0, T4 q1, T4 q2, T4 q3, V3 p, V3 d, float &t, V3 &position) {
     V3 n = v3(q0.x, q0.y, q0.z);
     V3 s = v3(q0.w, q1.x, q1.y);
     float num = n.x * (s.x - p.x) + n.y * (s.y - p.y) + n.z * (s.z - p.z);
@@ -120,8 +122,11 @@ PT_HD bool plane_test(float4 q0, float4 q1, float4 q2, float4 q3, V3 p, V3 d, fl
 }
 
 // ---- nearest hit by linear scan: reference src/scene.rs:263-297 ---------------------------------------
-// A later primitive replaces the current nearest only when strictly closer.
-PT_HD uint32_t nearest_brute(const float4 *sph, uint32_t n_sph, const float4 *pln, uint32_t n_pl, V3 p, V3 d, float &best_t) {
+// A later primitive replaces the current nearest only when strictly closer.  P4 is any pointer to a 4-float
+// vector (the kernels pass constant-address-space pointers so the wave-uniform primitive fetches become
+// scalar loads into SGPRs).
+template <class P4>
+PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p, V3 d, float &best_t) {
     uint32_t best = MISS;
     best_t = 0.0f;
     for (uint32_t i = 0; i < n_sph; ++i) {

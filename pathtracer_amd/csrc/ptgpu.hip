@@ -51,7 +51,7 @@ struct PtHandle {
     uint32_t batch = 0;            // samples per pixel per pass
     std::vector<Level> levels;
     std::vector<void *> level_allocs;
-    uint32_t *d_counts = nullptr;      // [n_levels * NSHARD]
+    uint32_t *d_counts = nullptr;      // [(n_levels + 1) * NSHARD * CSTRIDE]: per level, then the shadow-ray row
     uint32_t *d_shard_caps = nullptr;  // [n_levels]
     Counters *d_ctr = nullptr;
     bool fused = true;
@@ -159,7 +159,7 @@ __global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t sha
     uint64_t start = (uint64_t)q * shard_cap;
     uint32_t c = 0;
     if (start < n_records) c = (uint32_t)std::min<uint64_t>(shard_cap, n_records - start);
-    count0[q] = c;
+    count0[q * CSTRIDE] = c;
 }
 
 uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
@@ -189,7 +189,7 @@ int alloc_levels(PtHandle *h) {
     std::vector<uint32_t> caps(h->n_levels);
     h->levels.resize(h->n_levels);
     int rc;
-    if ((rc = dev_alloc(h, &h->d_counts, (size_t)h->n_levels * NSHARD))) return rc;
+    if ((rc = dev_alloc(h, &h->d_counts, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE))) return rc;
     if ((rc = dev_alloc(h, &h->d_shard_caps, (size_t)h->n_levels))) return rc;
     if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
     for (int l = 0; l <= D; ++l) {
@@ -202,7 +202,7 @@ int alloc_levels(PtHandle *h) {
         size_t n = (size_t)cap * NSHARD;
         Level &L = h->levels[l];
         L.shard_cap = cap;
-        L.count = h->d_counts + (size_t)l * NSHARD;
+        L.count = h->d_counts + (size_t)l * NSHARD * CSTRIDE;
         // one allocation per level, carved into the SoA arrays (16-byte arrays first)
         size_t bytes = n * rec_bytes;
         char *base = nullptr;
@@ -219,7 +219,7 @@ int alloc_levels(PtHandle *h) {
         L.meta = (uint32_t *)base;
     }
     HIPCHK(h, hipMemcpyAsync(h->d_shard_caps, caps.data(), caps.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, (size_t)h->n_levels * NSHARD * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PT_OK;
@@ -239,7 +239,7 @@ int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
     const uint32_t flat_grid = (uint32_t)std::min<uint64_t>(8192, (S + BLOCK - 1) / BLOCK);
     const size_t lds = h->lds_bytes;
 
-    HIPCHK(h, hipMemsetAsync(h->d_counts + NSHARD, 0, (size_t)D * NSHARD * 4, st));
+    HIPCHK(h, hipMemsetAsync(h->d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 1) * NSHARD * CSTRIDE * 4, st));  // levels 1..D + shadow row
     k_set_counts0<<<1, NSHARD, 0, st>>>(h->levels[0].count, S, h->levels[0].shard_cap);
     {
         Span s(h, PT_KERNEL_RAYGEN);
@@ -263,7 +263,8 @@ int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
     }
     {
         Span s(h, PT_KERNEL_TERMINAL);
-        k_terminal<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, h->levels[D], h->levels[D - 1], pp, h->d_ctr);
+        k_terminal<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, h->levels[D], h->levels[D - 1], pp,
+                                                   h->d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE);
     }
     for (int l = D - 1; l >= 1; --l) {
         Span s(h, PT_KERNEL_GATHER);
@@ -556,6 +557,27 @@ int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples) {
     return PT_OK;
 }
 
+int ptgpu_export_pixels32(PtHandle *h, void *dst_device) {
+    if (!h || !dst_device) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->sc.width * h->sc.height * 3 * 4;
+    HIPCHK(h, hipMemcpyAsync(dst_device, h->d_pixels32, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int ptgpu_import_pixels32(PtHandle *h, const void *src_device, uint64_t num_samples) {
+    if (!h || !src_device) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->sc.width * h->sc.height * 3 * 4;
+    HIPCHK(h, hipMemcpyAsync(h->d_pixels32, src_device, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->num_samples = num_samples;
+    return PT_OK;
+}
+
 int ptgpu_stream(PtHandle *h, void **stream) {
     if (!h || !stream) return PT_ERR_INVALID_ARGUMENT;
     *stream = (void *)h->stream;
@@ -570,7 +592,8 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         if (rc && rc != PT_ERR_QUEUE_OVERFLOW) return rc;
         Counters c;
         HIPCHK(h, hipMemcpy(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost));
-        out->rays = c.rays;
+        out->rays = c.rays + c.shadow;
+        out->shadow_rays = c.shadow;
         out->records = c.records;
         out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
     }

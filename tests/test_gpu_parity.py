@@ -1,0 +1,253 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact.  Primitive ids, u32 accumulators and display bytes are integers; the f32 radiance behind them
+is reproduced operation for operation (no FMA contraction, correctly rounded div/sqrt, deterministic
+transcendental functions on both sides), so even the quantised sums must be identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import hdri_scene, materials_scene
+from pathtracer_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_render(oracle, sc, n, max_depth=4, seed=314159265, sub_pixel_override=-1, sample_indices=None):
+    osc = oracle.OracleScene(sc)
+    opt = oracle.options(oracle.RNG_COUNTER, oracle.MATH_DET, seed=seed, max_depth=max_depth, sub_pixel_override=sub_pixel_override)
+    return osc, opt, osc.render(opt, n, sample_indices=sample_indices)
+
+
+def _gpu_render(binding, sc, n, **cfg):
+    with binding.PtGpu(**cfg) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(n)
+        p32, ns = gpu.read_pixels32()
+        p8 = gpu.read_pixels8()
+        st = gpu.stats()
+    return p32, p8, ns, st
+
+
+# ---- deterministic math on the device -------------------------------------------------------------------
+@pytest.mark.parametrize("fn,lo,hi", [(0, -10.0, 10.0), (1, -10.0, 10.0), (3, -110.0, 95.0), (4, -1.0, 1.0)])
+def test_det_math_unary_bit_exact(binding, oracle, fn, lo, hi):
+    rng = np.random.RandomState(fn + 11)
+    a = rng.uniform(lo, hi, 400000).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, np.inf, -np.inf, np.nan, 1e-45, 6.2831855, 3.1415927, 1e6, -1e6,
+                        1e20, 0.99999994, -0.99999994], dtype=np.float32)
+    a = np.concatenate([a, special])
+    with binding.PtGpu() as gpu:
+        got = gpu.eval_math(fn, a)
+    ref = oracle.math_eval(oracle.MATH_DET, fn, a)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_det_math_pow_atan2_bit_exact(binding, oracle):
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.uniform(0.0, 1.5, 300000), rng.uniform(-2.0, 50.0, 100000)]).astype(np.float32)
+    with binding.PtGpu() as gpu:
+        for y in (5.0, 1.0 / 2.2, 2.0, -1.5, 3.0, 0.0):
+            yy = np.full_like(x, np.float32(y))
+            got = gpu.eval_math(2, x, yy)
+            ref = oracle.math_eval(oracle.MATH_DET, 2, x, yy)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), y
+        sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 2.0, -2.0, 0.5, 3.0, -3.0], dtype=np.float32)
+        X, Y = np.meshgrid(sp, sp)
+        got = gpu.eval_math(2, X.ravel(), Y.ravel())
+        ref = oracle.math_eval(oracle.MATH_DET, 2, X.ravel(), Y.ravel())
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        yv = rng.uniform(-3, 3, 300000).astype(np.float32)
+        xv = rng.uniform(-3, 3, 300000).astype(np.float32)
+        got = gpu.eval_math(5, np.concatenate([yv, Y.ravel()]), np.concatenate([xv, X.ravel()]))
+        ref = oracle.math_eval(oracle.MATH_DET, 5, np.concatenate([yv, Y.ravel()]), np.concatenate([xv, X.ravel()]))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- primary-hit ids ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("jitter", [0, 1])
+def test_primary_ids_sample_scene_1024(binding, oracle, jitter):
+    sc = S.sample_scene(1024, 1024)
+    with binding.PtGpu(sub_pixel_override=jitter) as gpu:
+        gpu.upload_scene(sc)
+        ids = gpu.primary_ids(3)
+    osc = oracle.OracleScene(sc)
+    ref = osc.primary_ids(oracle.options(sub_pixel_override=jitter), 3)
+    assert np.array_equal(ids, ref)
+    if not jitter:
+        assert ids[512, 512] == 5  # centre ray: back wall (front wall is one-sided and faces away)
+    assert set(np.unique(ids)) <= {0, 1, 2, 3, 4, 5, 6, 7, 9}  # id 8 (front wall) is never visible
+
+
+def test_primary_ids_1080p_variant(binding, oracle):
+    sc = S.sample_scene(1920, 1080, camera_width=8.8888889)
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        ids = gpu.primary_ids(0)
+    ref = oracle.OracleScene(sc).primary_ids(oracle.options(), 0)
+    assert np.array_equal(ids, ref)
+
+
+# ---- accumulated radiance ----------------------------------------------------------------------------------------
+def test_sample_scene_pixels_bit_exact(binding, oracle):
+    sc = S.sample_scene(160, 120, camera_width=6.6666667)
+    p32, p8, ns, st = _gpu_render(binding, sc, 6)
+    osc, opt, (r32, r8, rays) = _oracle_render(oracle, sc, 6)
+    assert ns == 6
+    assert np.array_equal(p32, r32)
+    assert np.array_equal(p8, r8)
+    assert st["rays"] == rays
+    assert st["samples"] == 160 * 120 * 6
+
+
+def test_unfused_pipeline_matches(binding, oracle):
+    sc = S.sample_scene(96, 96)
+    a32, a8, _, sa = _gpu_render(binding, sc, 3, fuse_trace_shade=0)
+    b32, b8, _, sb = _gpu_render(binding, sc, 3, fuse_trace_shade=1)
+    _, _, (r32, r8, rays) = _oracle_render(oracle, sc, 3)
+    assert np.array_equal(a32, r32) and np.array_equal(b32, r32)
+    assert np.array_equal(a8, r8) and np.array_equal(b8, r8)
+    assert sa["rays"] == rays and sb["rays"] == rays
+
+
+@pytest.mark.parametrize("tone", [S.TONE_CLAMP, S.TONE_REINHARD, S.TONE_EXPOSURE])
+def test_all_materials_and_lights(binding, oracle, tone):
+    sc = materials_scene(80, 60, tone=tone, exposure=0.7)
+    p32, p8, ns, st = _gpu_render(binding, sc, 8)
+    _, _, (r32, r8, rays) = _oracle_render(oracle, sc, 8)
+    assert np.array_equal(p32, r32)
+    assert np.array_equal(p8, r8)
+    assert st["rays"] == rays
+    assert st["shadow_rays"] > 0  # the upward-facing light and the sphere light do get sampled
+
+
+def test_hdri_sky_exposure(binding, oracle):
+    sc = hdri_scene()
+    p32, p8, _, st = _gpu_render(binding, sc, 8)
+    _, _, (r32, r8, rays) = _oracle_render(oracle, sc, 8)
+    assert np.array_equal(p32, r32)
+    assert np.array_equal(p8, r8)
+    assert st["rays"] == rays
+
+
+def test_hdri_not_loaded_is_white(binding, oracle):
+    sc = hdri_scene()
+    sc.sky = S.Sky.hdri("pending.hdr", None)
+    p32, _, _, _ = _gpu_render(binding, sc, 2)
+    _, _, (r32, _, _) = _oracle_render(oracle, sc, 2)
+    assert np.array_equal(p32, r32)
+
+
+def test_depth_16_diffuse_room(binding, oracle):
+    sc = S.diffuse_room_scene(96, 54, n_spheres=12)
+    p32, p8, _, st = _gpu_render(binding, sc, 4, max_depth=16)
+    _, _, (r32, r8, rays) = _oracle_render(oracle, sc, 4, max_depth=16)
+    assert np.array_equal(p32, r32)
+    assert np.array_equal(p8, r8)
+    assert st["rays"] == rays
+
+
+@pytest.mark.parametrize("depth", [1, 2, 7])
+def test_other_depths(binding, oracle, depth):
+    sc = S.sample_scene(64, 64)
+    p32, _, _, st = _gpu_render(binding, sc, 3, max_depth=depth)
+    _, _, (r32, _, rays) = _oracle_render(oracle, sc, 3, max_depth=depth)
+    assert np.array_equal(p32, r32)
+    assert st["rays"] == rays
+
+
+def test_empty_scene_and_no_lights(binding, oracle):
+    sc = S.Scene()  # Scene::default: no primitives, white sky, 256x256
+    sc.camera.tone_mapping, sc.camera.exposure = S.TONE_EXPOSURE, 1.0
+    p32, p8, _, _ = _gpu_render(binding, sc, 2)
+    _, _, (r32, r8, _) = _oracle_render(oracle, sc, 2)
+    assert np.array_equal(p32, r32) and np.array_equal(p8, r8)
+    sc2 = S.sample_scene(48, 48)
+    sc2.emissive_planes.clear()  # no lights: the terminal sample is black instead of the reference's `% 0` panic
+    p32, _, _, _ = _gpu_render(binding, sc2, 2)
+    _, _, (r32, _, _) = _oracle_render(oracle, sc2, 2)
+    assert np.array_equal(p32, r32)
+
+
+def test_ragged_image_sizes(binding, oracle):
+    for w, h in [(1, 1), (33, 17), (65, 31)]:  # not multiples of the 32x32 tile nor of the 64-lane wave
+        sc = S.sample_scene(w, h, camera_width=5.0 * w / h)
+        p32, p8, _, _ = _gpu_render(binding, sc, 3)
+        _, _, (r32, r8, _) = _oracle_render(oracle, sc, 3)
+        assert np.array_equal(p32, r32) and np.array_equal(p8, r8), (w, h)
+
+
+# ---- host-visible state machine -----------------------------------------------------------------------------------
+def test_batching_and_incremental_render_are_equivalent(binding):
+    sc = S.sample_scene(64, 48, camera_width=6.6666667)
+    a, _, _, _ = _gpu_render(binding, sc, 7, samples_per_batch=1)
+    b, _, _, _ = _gpu_render(binding, sc, 7, samples_per_batch=4)
+    with binding.PtGpu(samples_per_batch=3) as gpu:
+        gpu.upload_scene(sc)
+        for n in (1, 2, 4):
+            gpu.render(n)
+        c, ns = gpu.read_pixels32()
+        assert ns == 7
+        gpu.clear()
+        z, ns0 = gpu.read_pixels32()
+        assert ns0 == 0 and not z.any() and not gpu.read_pixels8().any()
+        gpu.render(7)
+        d, _ = gpu.read_pixels32()
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+
+
+def test_sample_sharding_sums_to_single_gpu(binding):
+    """Two shards (as two ranks would render them) add up to exactly the unsharded accumulator."""
+    sc = S.sample_scene(72, 40, camera_width=9.0)
+    full, _, _, _ = _gpu_render(binding, sc, 6)
+    parts = []
+    for r in range(2):
+        p, _, ns, _ = _gpu_render(binding, sc, 3, shard_index=r, shard_count=2)
+        assert ns == 3
+        parts.append(p)
+    assert np.array_equal(parts[0] + parts[1], full)
+
+
+def test_export_import_accumulator(binding):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    sc = S.sample_scene(40, 24)
+    with binding.PtGpu() as g1, binding.PtGpu() as g2:
+        g1.upload_scene(sc); g2.upload_scene(sc)
+        g1.render(2)
+        ref, _ = g1.read_pixels32()
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), 40 * 24 * 3 * 4) == 0
+        g1.export_pixels32(buf.value)
+        g2.import_pixels32(buf.value, 2)
+        got, ns = g2.read_pixels32()
+        assert ns == 2 and np.array_equal(got, ref)
+        assert np.array_equal(g2.read_pixels8(), g1.read_pixels8())
+        hip.hipFree(buf)
+
+
+def test_errors_are_reported_not_thrown(binding):
+    with binding.PtGpu() as gpu:
+        with pytest.raises(binding.PtGpuError) as e:
+            gpu.render(1)
+        assert e.value.code == -4  # PT_ERR_NO_SCENE
+    with pytest.raises(binding.PtGpuError) as e:
+        binding.PtGpu(max_depth=0)
+    assert e.value.code == -1
+    with pytest.raises(binding.PtGpuError):
+        binding.PtGpu(shard_index=2, shard_count=2)
+
+
+def test_glass_queue_overflow_is_detected(binding):
+    """A scene that is all glass doubles the queue at every level; with branch_capacity 1 the level after the
+    first cannot hold it and the library must say so instead of dropping rays silently."""
+    sc = S.Scene(image_settings=S.ImageSettings(128, 128, True),
+                 camera=S.Camera((0.0, 0.0, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1.0, 1.0, 3.0, S.TONE_CLAMP, 1.0, 100.0),
+                 sky=S.Sky.constant((1.0, 1.0, 1.0)))
+    sc.add(S.Sphere((0.0, 0.0, 0.0), 2.0, S.Material.translucent(1.5)))
+    with binding.PtGpu(branch_capacity=1, samples_per_batch=1) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(1)  # 16384 primary rays, all on glass -> 32768 children for a level sized for ~1.25 x 16384
+        with pytest.raises(binding.PtGpuError) as e:
+            gpu.read_pixels32()
+        assert e.value.code == -5
