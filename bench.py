@@ -61,7 +61,11 @@ def main() -> None:
     ap.add_argument("--spp-per-step", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--max-depth", type=int, default=4)
+    ap.add_argument("--max-depth", type=int, default=0, help="0 = the workload's own (4; 16 for room)")
+    ap.add_argument("--workload", choices=["sample", "quads", "room"], default="sample",
+                    help="sample: the reference's scene (headline); quads: ~1M-rectangle height field (BVH); "
+                         "room: closed diffuse room at max_depth 16 (queue compaction)")
+    ap.add_argument("--grid", type=int, default=1000, help="quads: rectangles per side")
     ap.add_argument("--fused", type=int, default=-1)
     ap.add_argument("--batch", type=int, default=0, help="samples per pixel per pipeline pass (0 = library default)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events (no roofline block)")
@@ -85,7 +89,19 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    sc = S.sample_scene(args.width, args.height, camera_width=5.0 * args.width / args.height)
+    if args.workload == "sample":
+        sc = S.sample_scene(args.width, args.height, camera_width=5.0 * args.width / args.height)
+        wl = f"scenes/sample at {args.width}x{args.height} (camera.width {5.0 * args.width / args.height:.7f})"
+        depth = args.max_depth or 4
+    elif args.workload == "quads":
+        sc = S.quad_field_scene(args.width, args.height, grid=args.grid, n_spheres=1000)
+        wl = f"procedural {args.grid}x{args.grid} rectangle height field + 1000 spheres (seed 12345) at {args.width}x{args.height}, BVH"
+        depth = args.max_depth or 4
+    else:
+        sc = S.diffuse_room_scene(args.width, args.height)
+        wl = f"closed diffuse room, 27 primitives (seed 777) at {args.width}x{args.height}"
+        depth = args.max_depth or 16
+    args.max_depth = depth
     gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, max_depth=args.max_depth,
                         fuse_trace_shade=args.fused, samples_per_batch=args.batch, profile_events=0 if args.no_events else 1)
     gpu.upload_scene(sc)
@@ -122,8 +138,7 @@ def main() -> None:
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"scenes/sample at {args.width}x{args.height} (camera.width {5.0 * args.width / args.height:.7f}), "
-                                   f"max_depth {args.max_depth}, {args.spp_per_step} spp per step per GPU",
+            "config": {"workload": f"{wl}, max_depth {args.max_depth}, {args.spp_per_step} spp per step per GPU",
                        "spp_per_step": args.spp_per_step, "parallelism": f"sample-index shards x{world}",
                        "accumulated_spp": total_spp},
             "msamples_per_s": round(samples / elapsed / 1e6, 2),
@@ -137,7 +152,9 @@ def main() -> None:
             traced = st["rays"] - st["shadow_rays"]          # records of the traced levels
             children = st["records"] - st["samples"]         # records appended to levels >= 1
             if name == "trace_shade":
-                alg = 52.0 * traced + 36.0 * children         # read ray 32; write kind 4 + coef/val 16; write child 36
+                # per traced record: read ray 32 (not at level 0: primary rays are generated in the kernel),
+                # write kind 4 + coef-or-leaf-value 16; per appended child: write ray 32 + parent 4
+                alg = 52.0 * traced - 32.0 * st["samples"] + 36.0 * children
             elif name == "trace":
                 alg = 36.0 * traced                           # read ray 32, write prim id 4
             elif name == "shade":
@@ -163,6 +180,8 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": round(alg / n_launch, 1),
                 "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
             }
+        if st["bvh_nodes"]:
+            out["bvh"] = {"nodes": st["bvh_nodes"], "leaf_prims": st["bvh_leaf_prims"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_seconds, 8)
         print(json.dumps(out), flush=True)

@@ -188,6 +188,12 @@ static inline float ptd_powf(float x, float y) {
         return (xneg && yint == 1) ? -mag : mag;
     }
     if (xneg && yint == 0) return ptd_f32_from_bits(0x7fc00000u); /* negative base, non-integer */
+    if (yb == 0x40a00000u) { /* y == 5 (Schlick's Fresnel term): x^5 by three binary64 products; x*x is exact */
+        double a = (double)ptd_f32_from_bits(ax);
+        double a2 = a * a;
+        double v5 = (a2 * a2) * a;
+        return (float)(xneg ? -v5 : v5);
+    }
     double z = (double)y * ptd_log2d((double)ptd_f32_from_bits(ax));
     double v = ptd_exp2d(z);
     if (xneg && yint == 1) v = -v;

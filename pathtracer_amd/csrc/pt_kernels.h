@@ -110,6 +110,7 @@ __device__ __forceinline__ uint32_t my_shard() { return (blockIdx.x * (BLOCK / 6
 __device__ __forceinline__ uint32_t wave_global() { return blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t waves_in_grid() { return gridDim.x * (BLOCK / 64); }
 
+// Counter-RNG key of a pixel-sample; `sid` = local sample * n_pixels + pixel is the level-0 record index.
 __device__ __forceinline__ uint32_t sample_key_of(const DevScene &sc, const PassParams &pp, uint32_t sid) {
     uint32_t pixel = sid % pp.n_pixels, s_local = sid / pp.n_pixels;
     return rng_sample_key(sc.seed, pixel, pp.sample_first + s_local * pp.sample_stride);
@@ -127,15 +128,21 @@ __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, 
 }
 
 // ---- raygen: reference src/tracer.rs:125-142,628-631 -------------------------------------------------------
+// A ray record carries the sample's RNG key (not the sample id), so no level has to redo the pixel/sample split.
+__device__ __forceinline__ void primary_ray(const DevScene &sc, const PassParams &pp, uint32_t sid, V3 &o, V3 &d, uint32_t &skey) {
+    uint32_t pixel = sid % pp.n_pixels;
+    skey = sample_key_of(sc, pp, sid);
+    pinhole_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
+}
+
+// Only the two-kernel (trace, shade) pipeline stores primary rays; the fused kernel generates them in place.
 __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, Level L0, PassParams pp, uint32_t n_records) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_records; i += gridDim.x * BLOCK) {
-        uint32_t pixel = i % pp.n_pixels;
-        uint32_t x = pixel % sc.width, y = pixel / sc.width;
-        uint32_t skey = sample_key_of(sc, pp, i);
         V3 o, d;
-        pinhole_ray(sc, x, y, skey, o, d);
+        uint32_t skey;
+        primary_ray(sc, pp, i, o, d, skey);
         L0.rayA[i] = make_float4(o.x, o.y, o.z, d.x);
-        L0.rayB[i] = make_float4(d.y, d.z, u2f(i), u2f(1u));
+        L0.rayB[i] = make_float4(d.y, d.z, u2f(skey), u2f(1u));
     }
 }
 
@@ -151,12 +158,15 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
     }
 }
 
-// ---- shade (optionally fused with trace): reference src/tracer.rs:494-583 -------------------------------------
+// ---- shade (optionally fused with trace and, at level 0, with raygen): reference src/tracer.rs:494-583 ----------
 // `level` is this level's index l; the children go to Lnext (level l+1).  At l >= 1 a leaf stores its radiance
 // straight into its parent's val slot; at l == 0 it keeps it in its own coef for the resolve step.
-template <bool FUSED>
+// At the last traced level (children have depth 0) a child whose terminal light sample needs no shadow ray
+// (reference src/tracer.rs:472-476: Plane::sample said None, or there are no lights) is worth zero, which is
+// written into this node's val slot at once instead of queueing a record for k_terminal.
+template <bool FUSED, bool RAYGEN>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
-                                                 Counters *ctr) {
+                                                 uint32_t last_traced, Counters *ctr) {
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
@@ -164,17 +174,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, Level L, Level Lpr
         bool valid = tile_record(m, L, w, i);
         NodeOut out;
         out.n_children = 0;
-        uint32_t sid = 0, node = 0;
+        uint32_t skey = 0, node = 0;
         if (valid) {
-            float4 a = L.rayA[i], b = L.rayB[i];
-            V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
-            sid = f2u(b.z);
-            node = f2u(b.w);
+            V3 o, d;
+            if (RAYGEN) {
+                primary_ray(sc, pp, i, o, d, skey);
+                node = 1u;
+            } else {
+                float4 a = L.rayA[i], b = L.rayB[i];
+                o = v3(a.x, a.y, a.z); d = v3(a.w, b.x, b.y);
+                skey = f2u(b.z);
+                node = f2u(b.w);
+            }
             uint32_t prim;
             if (FUSED) { float t; prim = nearest_hit(sc, o, d, t); }
             else prim = L.hitprim[i];
-            uint32_t nkey = rng_node_key(sample_key_of(sc, pp, sid), node);
-            shade_hit(sc, o, d, prim, nkey, out);
+            shade_hit(sc, o, d, prim, rng_node_key(skey, node), out);
             if (out.kind == NK_LEAF) {
                 if (level == 0) {
                     L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
@@ -189,24 +204,37 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, Level L, Level Lpr
             L.meta[i] = out.kind;
         }
         bool has0 = valid && out.n_children >= 1, has1 = valid && out.n_children >= 2;
+        if (last_traced) {
+            V3 dir, rad;
+            float dist;
+            if (has0 && !terminal_sample(sc, out.o0, rng_node_key(skey, 2u * node), dir, dist, rad)) {
+                L.val0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                has0 = false;
+            }
+            if (has1 && !terminal_sample(sc, out.o1, rng_node_key(skey, 2u * node + 1u), dir, dist, rad)) {
+                L.val1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                has1 = false;
+            }
+        }
         uint32_t i0, i1;
         wave_append(Lnext, shard, has0, has1, i0, i1, ctr);
         if (has0) {
             Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
-            Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(sid), u2f(2u * node));
+            Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
             Lnext.parent[i0] = (i << 1);
         }
         if (has1) {
             Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
-            Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(sid), u2f(2u * node + 1u));
+            Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
             Lnext.parent[i1] = (i << 1) | 1u;
         }
     }
 }
 
 // ---- terminal level (depth == 0): reference src/tracer.rs:451-492 ------------------------------------------------
-// `shadow_count` is a row of per-shard counters like Level::count (zeroed every pass, summed by k_account).
-__global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, PassParams pp, uint32_t *shadow_count) {
+// Holds only the light samples that need a shadow ray (k_shade drops the others).  `shadow_count` is a row of
+// per-shard counters like Level::count (zeroed every pass, summed by k_account).
+__global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, uint32_t *shadow_count) {
     TileMap m = tile_map(L);
     uint32_t n_shadow = 0;
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
@@ -216,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
         if (valid) {
             float4 a = L.rayA[i], b = L.rayB[i];
             V3 o = v3(a.x, a.y, a.z);
-            uint32_t nkey = rng_node_key(sample_key_of(sc, pp, f2u(b.z)), f2u(b.w));
+            uint32_t nkey = rng_node_key(f2u(b.z), f2u(b.w));
             V3 value = v3(0.0f, 0.0f, 0.0f), dir, radiance;
             float dist;
             shadow = terminal_sample(sc, o, nkey, dir, dist, radiance);

@@ -226,6 +226,12 @@ PT_HD float powf_(float x, float y) {
         return (xneg && yint == 1) ? -mag : mag;
     }
     if (xneg && yint == 0) return u2f(0x7fc00000u);
+    if (yb == 0x40a00000u) {  // y == 5 (Schlick's Fresnel term): x^5 by three binary64 products; x*x is exact
+        double a = (double)u2f(ax);
+        double a2 = a * a;
+        double v5 = (a2 * a2) * a;
+        return (float)(xneg ? -v5 : v5);
+    }
     double z = (double)y * log2d((double)u2f(ax));
     double v = exp2d(z);
     if (xneg && yint == 1) v = -v;

@@ -241,7 +241,7 @@ int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
 
     HIPCHK(h, hipMemsetAsync(h->d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 1) * NSHARD * CSTRIDE * 4, st));  // levels 1..D + shadow row
     k_set_counts0<<<1, NSHARD, 0, st>>>(h->levels[0].count, S, h->levels[0].shard_cap);
-    {
+    if (!h->fused) {
         Span s(h, PT_KERNEL_RAYGEN);
         k_raygen<<<flat_grid, BLOCK, 0, st>>>(h->sc, h->levels[0], pp, S);
     }
@@ -249,21 +249,23 @@ int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
         Level &L = h->levels[l];
         Level &Lp = h->levels[l > 0 ? l - 1 : 0];
         Level &Ln = h->levels[l + 1];
+        const uint32_t last = (l == D - 1) ? 1u : 0u;
         if (h->fused) {
             Span s(h, PT_KERNEL_TRACE_SHADE);
-            k_shade<true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, h->d_ctr);
+            if (l == 0) k_shade<true, true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+            else k_shade<true, false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         } else {
             {
                 Span s(h, PT_KERNEL_TRACE);
                 k_trace<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L);
             }
             Span s(h, PT_KERNEL_SHADE);
-            k_shade<false><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, h->d_ctr);
+            k_shade<false, false><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         }
     }
     {
         Span s(h, PT_KERNEL_TERMINAL);
-        k_terminal<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, h->levels[D], h->levels[D - 1], pp,
+        k_terminal<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, h->levels[D], h->levels[D - 1],
                                                    h->d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE);
     }
     for (int l = D - 1; l >= 1; --l) {

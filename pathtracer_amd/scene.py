@@ -230,7 +230,7 @@ def quad_field_scene(width: int = 1920, height: int = 1080, grid: int = 1000, n_
     rng = np.random.RandomState(seed)
     sc = Scene(
         image_settings=ImageSettings(width, height, True),
-        camera=Camera((0.0, 18.0, 60.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 8.0 * width / height, 8.0, 10.0, TONE_CLAMP, 1.0, 100.0),
+        camera=Camera((0.0, 26.0, 62.0), (0.0, 0.0, 8.0), (0.0, 1.0, 0.0), 8.0 * width / height, 8.0, 10.0, TONE_CLAMP, 1.0, 100.0),
         sky=Sky.constant((0.5, 0.5, 0.5)),
     )
     cell = 100.0 / grid

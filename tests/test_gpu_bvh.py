@@ -1,0 +1,75 @@
+"""The BVH must return exactly what the reference's linear scan returns (reference src/scene.rs:263-297):
+same primitive id for every ray, hence the same accumulated image.  Checked against the oracle where the
+oracle finishes in seconds, and against the GPU's own linear scan (itself oracle-checked in
+test_gpu_parity.py) at sizes the oracle cannot reach."""
+import numpy as np
+import pytest
+
+from conftest import materials_scene
+from pathtracer_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _ids_and_pixels(binding, sc, accel, spp, **cfg):
+    with binding.PtGpu(accel=accel, **cfg) as gpu:
+        gpu.upload_scene(sc)
+        ids = [gpu.primary_ids(s) for s in range(2)]
+        gpu.render(spp)
+        p32, _ = gpu.read_pixels32()
+        st = gpu.stats()
+    return ids, p32, st
+
+
+@pytest.mark.parametrize("make", [lambda: S.sample_scene(128, 96, camera_width=6.6666667), lambda: materials_scene(96, 72),
+                                  lambda: S.diffuse_room_scene(96, 54, n_spheres=20)])
+def test_small_scenes_bvh_equals_linear_scan_and_oracle(binding, oracle, make):
+    sc = make()
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 4)
+    ids_l, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 4)
+    assert st_b["bvh_nodes"] > 0 and st_l["bvh_nodes"] == 0
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_b, p_l)
+    assert st_b["rays"] == st_l["rays"]
+    osc = oracle.OracleScene(sc)
+    opt = oracle.options()
+    assert np.array_equal(ids_b[1], osc.primary_ids(opt, 1))
+    r32, _, rays = osc.render(opt, 4)
+    assert np.array_equal(p_b, r32) and st_b["rays"] == rays
+
+
+def test_quad_field_10k_against_oracle(binding, oracle):
+    sc = S.quad_field_scene(96, 54, grid=100, n_spheres=100)
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_AUTO, 2)
+    assert st_b["bvh_nodes"] > 1000  # auto picks the BVH for 10k primitives
+    osc = oracle.OracleScene(sc)
+    opt = oracle.options()
+    for s in range(2):
+        assert np.array_equal(ids_b[s], osc.primary_ids(opt, s))
+    r32, _, rays = osc.render(opt, 2)  # bounce and shadow rays go through the BVH too
+    assert np.array_equal(p_b, r32)
+    assert st_b["rays"] == rays
+
+
+def test_quad_field_250k_bvh_equals_gpu_linear_scan(binding):
+    sc = S.quad_field_scene(160, 90, grid=500, n_spheres=500)
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 2)
+    ids_l, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 2)
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_b, p_l)
+    assert st_b["rays"] == st_l["rays"]
+    hit = ids_b[0] != 0xFFFFFFFF
+    assert hit.mean() > 0.4 and len(np.unique(ids_b[0])) > 1000  # the camera really looks at the field
+
+
+def test_unboundable_and_dead_planes(binding, oracle):
+    """A plane with parallel u, v has a NaN normal and can never be hit; one with a usable normal but a zero-length
+    v cannot be bounded and must still be tested for every ray."""
+    sc = S.sample_scene(64, 48, camera_width=6.6666667)
+    sc.add(S.Plane((0.0, 1.0, 0.0), (1.0, 0.0, 0.0), (2.0, 0.0, 0.0), S.Material.physically((1.0, 1.0, 1.0), 0.5, 0.0)))
+    ids_b, p_b, _ = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 2)
+    ids_l, p_l, _ = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 2)
+    assert np.array_equal(ids_b[0], ids_l[0]) and np.array_equal(p_b, p_l)
+    assert np.array_equal(ids_b[0], oracle.OracleScene(sc).primary_ids(oracle.options(), 0))
