@@ -15,7 +15,7 @@ import numpy as np
 from . import scene as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+LIB_PATH = os.environ.get("PTGPU_LIB", os.path.join(_HERE, "libptgpu.so"))  # override: A/B builds only
 
 PT_KERNEL_COUNT = 8
 KERNEL_NAMES = ["raygen", "trace", "shade", "trace_shade", "terminal", "gather", "resolve", "unused"]

@@ -32,6 +32,9 @@ constexpr int NSHARD = 64;
 constexpr int CSTRIDE = 32;  // u32 words between two shard counters: one 128-byte line each, because atomics on one
                              // line serialise (~90/us) no matter which word of it they hit
 constexpr int BLOCK = 256;
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4  // minimum waves per SIMD the shade kernel is compiled for (bounds its VGPR budget)
+#endif
 
 struct Level {
     float4 *rayA;       // (origin.xyz, dir.x)
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
 // (reference src/tracer.rs:472-476: Plane::sample said None, or there are no lights) is worth zero, which is
 // written into this node's val slot at once instead of queueing a record for k_terminal.
 template <bool FUSED, bool RAYGEN>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
+__global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();

@@ -1,0 +1,99 @@
+"""Statistical parity with the reference-faithful oracle, and size-independent checks at the full benchmark size.
+
+The reference's RNG is one racy global xorshift32 and its transcendental functions are the platform libm, so
+against THAT configuration (oracle: xorshift stream + libm) only the converged image can be compared: two
+independent Monte-Carlo estimates of the same per-pixel expectation E[quantise(gamma(tonemap(L)))].
+Tolerance (stated here, in 8-bit units of sum/n): RMSE <= 3.0 at 1024 spp, and the error must fall like
+1/sqrt(spp) (x16 samples -> x4 +- 35 %).  The estimator is the same on both sides (no Russian roulette, both glass
+lobes per sample, same light sampling), so there is no bias term to budget for.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _rmse(a, na, b, nb):
+    return float(np.sqrt(np.mean((a.astype(np.float64) / na - b.astype(np.float64) / nb) ** 2)))
+
+
+def test_converged_image_matches_reference_rng_and_libm(binding, oracle):
+    sc = S.sample_scene(128, 72, camera_width=8.8888889)
+    osc = oracle.OracleScene(sc)
+    ref = {}
+    for n in (64, 1024):
+        ref[n], _, _ = osc.render(oracle.options(oracle.RNG_XORSHIFT, oracle.MATH_LIBM), n, threads=8)
+    got = {}
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(64)
+        got[64], _ = gpu.read_pixels32()
+        gpu.render(1024 - 64)
+        got[1024], n = gpu.read_pixels32()
+        assert n == 1024
+    e64, e1024 = _rmse(got[64], 64, ref[64], 64), _rmse(got[1024], 1024, ref[1024], 1024)
+    assert e1024 <= 3.0, e1024
+    assert 4.0 * 0.65 <= e64 / e1024 <= 4.0 * 1.35, (e64, e1024)
+    # no systematic offset: the mean image levels agree far better than the per-pixel noise
+    for c in range(3):
+        assert abs(got[1024][..., c].mean() - ref[1024][..., c].mean()) / 1024 < 0.25
+
+
+def test_deterministic_math_vs_libm_same_rng(binding, oracle):
+    """Same counter RNG, libm instead of the deterministic functions: identical for all but a handful of samples
+    (a 1-ulp difference has to land exactly on a quantisation step or flip a specular/diffuse pick)."""
+    sc = S.sample_scene(96, 54, camera_width=8.8888889)
+    osc = oracle.OracleScene(sc)
+    det, _, _ = osc.render(oracle.options(oracle.RNG_COUNTER, oracle.MATH_DET), 16)
+    lib, _, _ = osc.render(oracle.options(oracle.RNG_COUNTER, oracle.MATH_LIBM), 16)
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(16)
+        got, _ = gpu.read_pixels32()
+    assert np.array_equal(got, det)
+    assert (got != lib).mean() < 0.02
+    assert np.abs(got.astype(np.int64) - lib.astype(np.int64)).mean() < 0.5
+
+
+def test_full_size_1080p_properties(binding, oracle):
+    """At the benchmark's size (1920x1080) the oracle is too slow for a pixel-for-pixel render, so check what does
+    not depend on size: sharded + combined == unsharded (linearity of the integer accumulator), incremental ==
+    one-shot, pixels8 is the documented function of pixels32, accumulator bounds, ray bookkeeping."""
+    sc = S.sample_scene(1920, 1080, camera_width=8.8888889)
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(6)
+        full, n = gpu.read_pixels32()
+        p8 = gpu.read_pixels8()
+        st = gpu.stats()
+        gpu.clear()
+        gpu.render(2); gpu.render(1); gpu.render(3)
+        again, _ = gpu.read_pixels32()
+    assert n == 6 and np.array_equal(full, again)
+    parts = []
+    for r in range(3):
+        with binding.PtGpu(shard_index=r, shard_count=3) as g:
+            g.upload_scene(sc)
+            g.render(2)
+            parts.append(g.read_pixels32()[0])
+    assert np.array_equal(parts[0] + parts[1] + parts[2], full)
+    assert full.max() <= 6 * 255 and full.min() >= 0
+    assert np.array_equal(p8, oracle.OracleScene(sc).assign_pixels8(full, 6))
+    P = 1920 * 1080
+    assert st["samples"] == 6 * P
+    assert 6 * P <= st["rays"] <= 6 * P * 31 + st["shadow_rays"]  # >= one ray per sample, <= a full glass tree
+    assert st["records"] >= st["rays"] - st["shadow_rays"]
+    # the light (id 9) region saturates: every sample there quantises to 255
+    ids = None
+    with binding.PtGpu(sub_pixel_override=0) as g:
+        g.upload_scene(sc)
+        ids = g.primary_ids(0)
+    inner = np.zeros_like(ids, dtype=bool)
+    # the jittered sample lies in [x,x+1]x[y,y+1]; its four corners are un-jittered sample points of this 3x3 block
+    inner[1:-1, 1:-1] = True
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            inner[1:-1, 1:-1] &= ids[dy:ids.shape[0] - 2 + dy, dx:ids.shape[1] - 2 + dx] == 9
+    assert inner.sum() > 1000 and np.all(full[inner] == 6 * 255)
