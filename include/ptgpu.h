@@ -177,6 +177,10 @@ void ptgpu_plane_normals(PtPlane *planes, uint64_t n);   /* fills planes[i].norm
 /* Device-side evaluation of one deterministic math function over n arguments (test hook for the
  * sin/cos/pow/exp/acos/atan2 replacements the kernels use): fn 0 sin, 1 cos, 2 pow, 3 exp, 4 acos, 5 atan2. */
 int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n);
+/* Device self-test of the gamma quantiser's lookup table (the resolve kernel's fast path for
+ * Pixel32::from_unit(gamma_correction(x)), src/tracer.rs:609-616 + src/common.rs:78-82): compares it with the direct
+ * powf evaluation for EVERY float in [0,1] plus ranges around the edges; *mismatches must come back 0. */
+int ptgpu_selftest_gamma(PtHandle *h, uint64_t *mismatches);
 
 #ifdef __cplusplus
 }

@@ -107,9 +107,10 @@ def load_library() -> C.CDLL:
     lib.ptgpu_plane_normals.argtypes = [C.c_void_p, C.c_uint64]
     lib.ptgpu_plane_normals.restype = None
     lib.ptgpu_eval_math.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.ptgpu_selftest_gamma.argtypes = [H, C.POINTER(C.c_uint64)]
     for name in ("ptgpu_create", "ptgpu_upload_scene", "ptgpu_clear", "ptgpu_render", "ptgpu_sync", "ptgpu_read_pixels32",
                  "ptgpu_read_pixels8", "ptgpu_render_primary_ids", "ptgpu_device_pixels32", "ptgpu_set_num_samples",
-                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32"):
+                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32", "ptgpu_selftest_gamma"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -259,6 +260,11 @@ class PtGpu:
             "kernel_launches": {KERNEL_NAMES[k]: st.kernel_launches[k] for k in range(PT_KERNEL_COUNT)},
             "kernel_ms": {KERNEL_NAMES[k]: st.kernel_ms[k] for k in range(PT_KERNEL_COUNT)},
         }
+
+    def selftest_gamma(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.lib.ptgpu_selftest_gamma(self.h, C.byref(n)))
+        return int(n.value)
 
     def eval_math(self, fn: int, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float32)

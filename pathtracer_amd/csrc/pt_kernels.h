@@ -284,25 +284,29 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
 }
 
 // ---- resolve: reference src/tracer.rs:634-643 (tone map, gamma, Pixel32::from_unit, add_pixel32) --------------------------
-// u32 adds are exact and order independent, so atomics keep the result deterministic when a pass holds
-// several samples of one pixel.
-__global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassParams pp, uint32_t n_records, uint32_t *pixels32) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_records; i += gridDim.x * BLOCK) {
-        uint32_t kind = L0.meta[i];
-        float4 c = L0.coef[i];
-        V3 value = v3(c.x, c.y, c.z);
-        if (kind != NK_LEAF) {
+// One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + pixel) into
+// its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
+__global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassParams pp, uint32_t spp, uint32_t *pixels32) {
+    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < pp.n_pixels; pixel += gridDim.x * BLOCK) {
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll 2
+        for (uint32_t s = 0; s < spp; ++s) {
+            uint32_t i = s * pp.n_pixels + pixel;
+            // all three loads are issued before any is consumed (val0 of a leaf is never written: ignored below)
+            uint32_t kind = L0.meta[i];
+            float4 c = L0.coef[i];
             float4 a = L0.val0[i];
             float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kind == NK_GLASS) b = L0.val1[i];
-            value = node_value(kind, value, c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+            V3 value = v3(c.x, c.y, c.z);
+            if (kind != NK_LEAF) value = node_value(kind, value, c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+            uint32_t q[3];
+            tonemap_gamma_quantise(sc, value, q);
+            acc0 += q[0]; acc1 += q[1]; acc2 += q[2];
         }
-        uint32_t q[3];
-        tonemap_gamma_quantise(sc, value, q);
-        uint32_t pixel = i % pp.n_pixels;
-        atomicAdd(&pixels32[3 * pixel + 0], q[0]);
-        atomicAdd(&pixels32[3 * pixel + 1], q[1]);
-        atomicAdd(&pixels32[3 * pixel + 2], q[2]);
+        pixels32[3 * pixel + 0] += acc0;
+        pixels32[3 * pixel + 1] += acc1;
+        pixels32[3 * pixel + 2] += acc2;
     }
 }
 
@@ -310,22 +314,27 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassPa
 // Adds this pass's record/ray counts to the running totals: rays = records of the traced levels 0..D-1;
 // row n_levels of `counts` holds the shadow rays counted by k_terminal.
 __global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, Counters *ctr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave: lane q sums shard q over the levels, then a shuffle reduction
+    const int q = threadIdx.x & 63;
     unsigned long long rec = 0, rays = 0;
     for (int l = 0; l < n_levels; ++l) {
-        unsigned long long n = 0;
-        for (int q = 0; q < NSHARD; ++q) {
-            uint32_t c = counts[(l * NSHARD + q) * CSTRIDE];
-            n += c < shard_caps[l] ? c : shard_caps[l];
-        }
+        uint32_t c = counts[(l * NSHARD + q) * CSTRIDE];
+        uint32_t cap = shard_caps[l];
+        unsigned long long n = c < cap ? c : cap;
         rec += n;
         if (l < n_levels - 1) rays += n;
     }
-    unsigned long long shadow = 0;
-    for (int q = 0; q < NSHARD; ++q) shadow += counts[(n_levels * NSHARD + q) * CSTRIDE];
-    ctr->records += rec;
-    ctr->rays += rays;
-    ctr->shadow += shadow;
+    unsigned long long shadow = counts[(n_levels * NSHARD + q) * CSTRIDE];
+    for (int o = 32; o > 0; o >>= 1) {
+        rec += __shfl_down(rec, o);
+        rays += __shfl_down(rays, o);
+        shadow += __shfl_down(shadow, o);
+    }
+    if (q == 0) {
+        ctr->records += rec;
+        ctr->rays += rays;
+        ctr->shadow += shadow;
+    }
 }
 
 // Backbuffer.pixels8: reference src/tracer.rs:271-282
@@ -348,6 +357,16 @@ __global__ __launch_bounds__(BLOCK) void k_primary_ids(DevScene sc, uint32_t sam
         float t;
         ids[pixel] = nearest_hit(sc, o, d, t);
     }
+}
+
+// Self-test: table lookup vs direct evaluation of the gamma quantiser for every float bit pattern in [first, last].
+__global__ void k_check_gamma(const float *table, uint32_t first, uint32_t last, unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    for (uint64_t b = (uint64_t)first + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b <= last; b += (uint64_t)gridDim.x * blockDim.x) {
+        float x = u2f((uint32_t)b);
+        if (gamma_quantise(table, x) != gamma_quantise_direct(x)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // Test hook: the deterministic math functions as the kernels evaluate them.

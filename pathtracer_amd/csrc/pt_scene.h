@@ -44,6 +44,7 @@ struct DevScene {
     V3 cam_origin, cam_su, cam_sv, cam_pos;
     int tone; float exposure; float iso_factor;
     int sky_kind; V3 sky_radiance; const float *sky_pixels; uint32_t sky_w, sky_h;
+    const float *gamma_table;  // [256] smallest x with trunc(255 * x^(1/2.2)) >= k (see gamma_quantise); may be null
     uint32_t width, height;
     int jitter;
     uint32_t seed;
@@ -379,6 +380,24 @@ PT_HD bool terminal_sample(const DevScene &sc, V3 origin, uint32_t node_key, V3 
 
 // ---- tone mapping + gamma + quantisation: reference src/tracer.rs:586-616,634-641, src/common.rs:44-57,78-82
 PT_HD float clampf32(float mn, float mx, float x) { if (x > mx) return mx; else if (x < mn) return mn; else return x; }
+// Pixel32::from_unit(gamma_correction(x)) for one channel: trunc(255 * x^(1/2.2)) saturating (src/tracer.rs:609-616,
+// src/common.rs:78-82).  The result is a step function of x, so for 0 <= x <= 1 it is looked up by bisection in the
+// table of its 255 step positions, built on the host with the SAME powf_ (PtHandle self-test checks all 2^30
+// floats of [0,1] against the direct evaluation).  Anything else (NaN, negative, > 1) takes the direct route.
+PT_HD uint32_t gamma_quantise_direct(float x) { return f32_as_u32(det::powf_(x, 1.0f / 2.2f) * 255.0f); }
+PT_HD uint32_t gamma_quantise(const float *table, float x) {
+    if (table != nullptr && x >= 0.0f && x <= 1.0f) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = 128; step != 0; step >>= 1) {
+            uint32_t k = lo + step;
+            if (table[k] <= x) lo = k;
+        }
+        return lo;
+    }
+    return gamma_quantise_direct(x);
+}
+
 PT_HD void tonemap_gamma_quantise(const DevScene &sc, V3 hdr, uint32_t q[3]) {
     V3 ldr;
     if (sc.tone == TONE_CLAMP) ldr = v3(clampf32(0.0f, 1.0f, hdr.x), clampf32(0.0f, 1.0f, hdr.y), clampf32(0.0f, 1.0f, hdr.z));
@@ -387,10 +406,9 @@ PT_HD void tonemap_gamma_quantise(const DevScene &sc, V3 hdr, uint32_t q[3]) {
         float e = sc.exposure;
         ldr = v3(1.0f - det::expf_(-e * hdr.x), 1.0f - det::expf_(-e * hdr.y), 1.0f - det::expf_(-e * hdr.z));
     }
-    const float GAMMA = 1.0f / 2.2f;
-    q[0] = f32_as_u32(det::powf_(ldr.x, GAMMA) * 255.0f);
-    q[1] = f32_as_u32(det::powf_(ldr.y, GAMMA) * 255.0f);
-    q[2] = f32_as_u32(det::powf_(ldr.z, GAMMA) * 255.0f);
+    q[0] = gamma_quantise(sc.gamma_table, ldr.x);
+    q[1] = gamma_quantise(sc.gamma_table, ldr.y);
+    q[2] = gamma_quantise(sc.gamma_table, ldr.z);
 }
 
 // ---- primary rays: reference src/tracer.rs:125-142 ------------------------------------------------------

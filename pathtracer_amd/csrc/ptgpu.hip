@@ -33,7 +33,7 @@ struct PtHandle {
     DevScene sc{};
     // device scene buffers
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
-    float *d_sky = nullptr;
+    float *d_sky = nullptr, *d_gamma = nullptr;
     BvhNode *d_bvh_nodes = nullptr;
     uint32_t *d_bvh_prims = nullptr, *d_bvh_always = nullptr;
     uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
@@ -96,7 +96,7 @@ void dev_free(T *&p) {
 }
 
 void free_scene(PtHandle *h) {
-    dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky);
+    dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
     dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_prims); dev_free(h->d_bvh_always);
     dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
     for (void *p : h->level_allocs) (void)hipFree(p);
@@ -274,7 +274,7 @@ int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
     }
     {
         Span s(h, PT_KERNEL_RESOLVE);
-        k_resolve<<<flat_grid, BLOCK, 0, st>>>(h->sc, h->levels[0], pp, S, h->d_pixels32);
+        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(h->sc, h->levels[0], pp, spp, h->d_pixels32);
     }
     k_account<<<1, 64, 0, st>>>(h->d_counts, h->d_shard_caps, h->n_levels, h->d_ctr);
     HIPCHK(h, hipGetLastError());
@@ -422,6 +422,20 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
         HIPCHK(h, hipMemcpy(h->d_sky, s->sky.pixels, n * 4, hipMemcpyHostToDevice));
         sc.sky_pixels = h->d_sky;
         sc.sky_w = (uint32_t)s->sky.width; sc.sky_h = (uint32_t)s->sky.height;
+    }
+    {   // step positions of trunc(255 * x^(1/2.2)) on [0,1], by bisection over the (monotone) f32 bit patterns
+        std::vector<float> table(256, 0.0f);
+        for (uint32_t k = 1; k < 256; ++k) {
+            uint32_t lo = 0, hi = 0x3f800000u;  // quantise(lo) < k <= quantise(hi): 0 -> 0, 1.0 -> 255
+            while (hi - lo > 1) {
+                uint32_t mid = lo + (hi - lo) / 2;
+                if (gamma_quantise_direct(u2f(mid)) >= k) hi = mid; else lo = mid;
+            }
+            table[k] = u2f(hi);
+        }
+        if ((rc = dev_alloc(h, &h->d_gamma, 256))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_gamma, table.data(), 256 * 4, hipMemcpyHostToDevice));
+        sc.gamma_table = h->d_gamma;
     }
     sc.width = s->width; sc.height = s->height;
     sc.jitter = h->cfg.sub_pixel_override < 0 ? (s->sub_pixel_sampling != 0) : (h->cfg.sub_pixel_override != 0);
@@ -638,6 +652,25 @@ void ptgpu_plane_normal(PtVec3 u, PtVec3 v, PtVec3 *out) {
 void ptgpu_plane_normals(PtPlane *planes, uint64_t n) {
     if (!planes) return;
     for (uint64_t i = 0; i < n; ++i) ptgpu_plane_normal(planes[i].u, planes[i].v, &planes[i].normal);
+}
+
+int ptgpu_selftest_gamma(PtHandle *h, uint64_t *mismatches) {
+    if (!h || !mismatches) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long *d = nullptr, host = 0;
+    HIPCHK(h, hipMalloc((void **)&d, 8));
+    HIPCHK(h, hipMemsetAsync(d, 0, 8, h->stream));
+    k_check_gamma<<<4096, 256, 0, h->stream>>>(h->sc.gamma_table, 0u, 0x3f800000u, d);          // +0 .. 1.0
+    k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x3f800001u, 0x3f810000u, d);    // just above 1
+    k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x80000000u, 0x80010000u, d);    // -0 and small negatives
+    k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x7f7f0000u, 0x7fc10000u, d);    // huge, inf, NaNs
+    hipError_t e = hipMemcpyAsync(&host, d, 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(h, PT_ERR_HIP, hipGetErrorString(e));
+    *mismatches = host;
+    return PT_OK;
 }
 
 int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n) {

@@ -271,3 +271,54 @@ def quad_field_scene(width: int = 1920, height: int = 1080, grid: int = 1000, n_
     # overhead light, normal u x v = (0,-1,0) facing the field
     sc.add(Plane((-30.0, 40.0, -30.0), (60.0, 0.0, 0.0), (0.0, 0.0, 60.0), Material.emissive((6.0, 6.0, 6.0))))
     return sc
+
+
+def _f(x) -> str:
+    """A float in the `.scene` dialect: digits '.' digits, no exponent (reference src/parser.rs:615-633); shortest
+    text that reads back to the same f32."""
+    return np.format_float_positional(np.float32(x), unique=True, trim="0")
+
+
+def _v(v) -> str:
+    return "(" + ", ".join(_f(c) for c in v) + ")"
+
+
+def _material_text(kind, color, roughness, metalness, ior) -> str:
+    if kind == MAT_EMISSIVE:
+        return "emissive {\n        radiance = %s\n    }" % _v(color)
+    if kind == MAT_TRANSLUCENT:
+        return "translucent {\n        ior = %s\n    }" % _f(ior)
+    if kind == MAT_PHYSICALLY:
+        return ("physically {\n        reflectivity = %s\n        roughness = %s\n        metalness = %s\n    }"
+                % (_v(color), _f(roughness), _f(metalness)))
+    raise ValueError("the .scene grammar has no syntax for Mirror / None materials (reference src/parser.rs:275-292)")
+
+
+def to_text(scene: Scene) -> str:
+    """The scene in the reference's `.scene` dialect (field order and newline rules of reference
+    src/parser.rs:114-426), loadable by the unchanged Rust parser and by pathtracer_amd/host/parser.cpp."""
+    out = []
+    im, cam = scene.image_settings, scene.camera
+    out.append("image {\n    width = %d\n    height = %d\n    sub_pixel_sampling = true\n}\n" % (im.width, im.height))
+    if scene.sky.kind == SKY_HDRI:
+        out.append("sky {\n    hdri {\n        path = %s\n    }\n}\n" % scene.sky.path)
+    else:
+        out.append("sky {\n    constant {\n        radiance = %s\n    }\n}\n" % _v(scene.sky.radiance))
+    tm = {TONE_CLAMP: "clamp", TONE_REINHARD: "reinhard"}.get(cam.tone_mapping, "exposure { value = %s }" % _f(cam.exposure))
+    out.append("camera {\n    position = %s\n    target = %s\n    up = %s\n    width = %s\n    height = %s\n    z_near = %s\n"
+               "    tone_mapping = %s\n    iso = %s\n}\n" % (_v(cam.position), _v(cam.target), _v(cam.up), _f(cam.width), _f(cam.height),
+                                                              _f(cam.z_near), tm, _f(cam.iso)))
+    sp, pl, es, ep = scene.arrays()
+    for arr in (pl, ep):
+        for p in arr:
+            m = p["material"]
+            out.append("plane {\n    origin = %s\n    u = %s\n    v = %s\n    material = %s\n}\n" % (
+                _v(p["origin"]), _v(p["u"]), _v(p["v"]),
+                _material_text(int(m["kind"]), m["color"], m["roughness"], m["metalness"], m["ior"])))
+    for arr in (sp, es):
+        for s in arr:
+            m = s["material"]
+            out.append("sphere {\n    origin = %s\n    radius = %s\n    material = %s\n}\n" % (
+                _v(s["origin"]), _f(s["radius"]),
+                _material_text(int(m["kind"]), m["color"], m["roughness"], m["metalness"], m["ior"])))
+    return "\n".join(out)

@@ -1,0 +1,49 @@
+"""Folds the rocprofv3 counter CSVs written by profiles/collect.sh into per-kernel, per-launch numbers.
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-byte request of a wide coalesced
+read, i.e. half the bytes: it is doubled here (this pipeline reads 16 B per lane from consecutive records).
+WRITE_SIZE is exact for 16-byte-per-lane stores.  Output: <out>/<tag>_counters.json and <out>/<tag>_hbm_traffic.json
+(HBM bytes per launch per kernel class, the `traffic` field of bench.py's roofline block).
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+CLASS = [("k_shade<true", "trace_shade"), ("k_shade<false", "shade"), ("k_trace", "trace"), ("k_terminal", "terminal"),
+         ("k_gather", "gather"), ("k_resolve", "resolve"), ("k_raygen", "raygen")]
+
+
+def klass(name):
+    for key, c in CLASS:
+        if key in name:
+            return c
+    return None
+
+
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(lambda: collections.defaultdict(set))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
+    for f in glob.glob(f"{out}/{tag}_{sub}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            c = klass(r["Kernel_Name"])
+            if c is None:
+                continue
+            agg[c][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[c][r["Counter_Name"]].add(r["Dispatch_Id"])
+res, traffic = {}, {}
+for c, v in agg.items():
+    res[c] = {}
+    for name, total in v.items():
+        n = max(1, len(launches[c][name]))
+        res[c][name] = {"total": total, "launches": n, "per_launch": total / n}
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        rd = 2.0 * 1024.0 * res[c]["FETCH_SIZE"]["per_launch"]
+        wr = 1024.0 * res[c]["WRITE_SIZE"]["per_launch"]
+        res[c]["hbm_bytes_per_launch"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr}
+        traffic[c] = rd + wr
+json.dump(res, open(f"{out}/{tag}_counters.json", "w"), indent=1)
+json.dump(traffic, open(f"{out}/{tag}_hbm_traffic.json", "w"), indent=1)
+print(json.dumps(traffic))

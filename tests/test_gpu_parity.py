@@ -64,6 +64,14 @@ def test_det_math_pow_atan2_bit_exact(binding, oracle):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_gamma_table_is_exact_for_every_float_in_unit_interval(binding):
+    """The resolve kernel looks trunc(255*x^(1/2.2)) up in a 255-entry step table; the device checks the lookup
+    against the direct deterministic powf for all 2^30 floats in [0,1] (and NaN/negative/>1 edge ranges)."""
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(S.sample_scene(8, 8))
+        assert gpu.selftest_gamma() == 0
+
+
 # ---- primary-hit ids ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("jitter", [0, 1])
 def test_primary_ids_sample_scene_1024(binding, oracle, jitter):
