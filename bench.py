@@ -78,7 +78,7 @@ def main() -> None:
     from pathtracer_amd import binding, distributed as D, scene as S
 
     rank, world, local_rank = D.env_rank()
-    if world > 1:
+    if world > 1 or os.environ.get("PTGPU_FORCE_COLLECTIVE"):
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
@@ -108,7 +108,7 @@ def main() -> None:
     for _ in range(args.warmup):
         gpu.render(args.spp_per_step)
     gpu.sync()
-    if world > 1:
+    if dist.is_initialized():
         D.combine_accumulators(gpu, args.warmup * args.spp_per_step)  # warms RCCL up too
     gpu.clear()
 
@@ -187,7 +187,7 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
     gpu.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,7 +32,7 @@ def allreduce_sum_(tensor):
     """In-place SUM all-reduce of an int32 accumulator tensor over the default process group (no-op for one rank).
     u32 sums stay below 2^31 for any practical sample count (255 per sample), so the int32 view is exact."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PTGPU_FORCE_COLLECTIVE")):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
 
@@ -43,8 +43,8 @@ def combine_accumulators(gpu, local_samples: int):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
-        return local_samples
+    if world == 1 and not (dist.is_initialized() and os.environ.get("PTGPU_FORCE_COLLECTIVE")):
+        return local_samples  # (the env switch runs the export -> all-reduce -> import path on one rank, for testing)
     n_words = gpu.width * gpu.height * 3
     buf = torch.empty(n_words, dtype=torch.int32, device=torch.device("cuda", gpu.cfg.device))
     gpu.export_pixels32(buf.data_ptr())

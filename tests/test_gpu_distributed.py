@@ -1,0 +1,30 @@
+"""The RCCL combine path of bench.py, as far as one GPU can exercise it: launched by torch.distributed.run the way
+the scaling bench is, one rank, with the switch that forces export -> nccl all_reduce -> import on a single rank.
+(The N > 1 arithmetic is covered by tests/test_distributed_gloo.py and test_sample_sharding_sums_to_single_gpu.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_under_torchrun_with_nccl_collective():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PTGPU_FORCE_COLLECTIVE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["accumulated_spp"] == 8 and d["value"] > 0
+    assert d["roofline"]["kernel"] == "trace_shade" and 0 < d["roofline"]["frac"] < 1
