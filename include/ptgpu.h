@@ -104,7 +104,8 @@ typedef struct {
     uint32_t samples_per_batch;   /* samples per pixel traced per pipeline pass; 0 = auto */
     uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records; 0 = 16 */
     int32_t accel;                /* PT_ACCEL_* */
-    int32_t fuse_trace_shade;     /* 1: one kernel per level does intersection + shading; 0: two kernels; -1: auto */
+    int32_t fuse_trace_shade;     /* 0: trace and shade kernels; 1: one fused kernel per level; 2: fused, and each block regroups
+                                     its rays by material arm before shading; -1: auto (= 2) */
     int32_t profile_events;       /* 1: bracket kernels with HIP events and report per-kernel time in PtStats */
 } PtConfig;
 
@@ -120,6 +121,7 @@ typedef struct {
     uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */
     double kernel_ms[PT_KERNEL_COUNT];        /* since clear (profile_events only) */
     uint64_t device_bytes;                    /* device memory held by the handle */
+    uint64_t debug_cycles[8];                 /* per-phase shader cycles of the fused kernel; diagnostic builds only, else 0 */
 } PtStats;
 
 typedef struct PtHandle PtHandle;

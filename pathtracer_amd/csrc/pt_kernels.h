@@ -56,7 +56,14 @@ struct PassParams {
 };
 
 // device-side counters (one allocation)
-struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow; };
+struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow; unsigned long long stamps[8]; };
+
+// Diagnostic builds (-DPT_STAMPS) time the phases of the fused kernel with s_memtime; never part of a shipped build.
+#ifdef PT_STAMPS
+#define PT_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp_acc[k] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -89,24 +96,35 @@ __device__ __forceinline__ bool tile_record(const TileMap &m, const Level &L, ui
     return off < cq;
 }
 
-// Reserve room in `L` for this wave's children; every lane of the wave must call it.
-__device__ __forceinline__ void wave_append(const Level &L, uint32_t shard, bool &has0, bool &has1, uint32_t &i0, uint32_t &i1,
-                                            Counters *ctr) {
-    unsigned long long m0 = __ballot(has0), m1 = __ballot(has1);
-    uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), total = n0 + n1;
+// Reserve room in `L` for this wave's children, in two steps so the returning atomic can stay in flight while the
+// wave keeps computing: wave_reserve issues it (lane 0), wave_resolve consumes the result.  Every lane of the wave
+// must call both.
+struct Reservation { unsigned long long m0, m1; uint32_t base; };
+
+__device__ __forceinline__ Reservation wave_reserve(const Level &L, uint32_t shard, bool has0, bool has1) {
+    Reservation r;
+    r.m0 = __ballot(has0);
+    r.m1 = __ballot(has1);
+    r.base = 0;
+    uint32_t total = (uint32_t)__popcll(r.m0) + (uint32_t)__popcll(r.m1);
+    if (total != 0 && lane_id() == 0) r.base = atomicAdd(&L.count[shard * CSTRIDE], total);
+    return r;
+}
+
+__device__ __forceinline__ void wave_resolve(const Level &L, uint32_t shard, const Reservation &r, bool &has0, bool &has1, uint32_t &i0,
+                                             uint32_t &i1, Counters *ctr) {
+    uint32_t n0 = (uint32_t)__popcll(r.m0), n1 = (uint32_t)__popcll(r.m1), total = n0 + n1;
     i0 = i1 = 0;
     if (total == 0) return;
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(&L.count[shard * CSTRIDE], total);
-    base = __shfl(base, 0);
+    uint32_t base = __shfl(r.base, 0);
     if (base + total > L.shard_cap) {  // never drop silently: the host turns this into PT_ERR_QUEUE_OVERFLOW
         if (lane_id() == 0) atomicOr(&ctr->overflow, 1u);
         has0 = has1 = false;
         return;
     }
     unsigned long long lt = (1ull << lane_id()) - 1ull;
-    i0 = shard * L.shard_cap + base + (uint32_t)__popcll(m0 & lt);
-    i1 = shard * L.shard_cap + base + n0 + (uint32_t)__popcll(m1 & lt);
+    i0 = shard * L.shard_cap + base + (uint32_t)__popcll(r.m0 & lt);
+    i1 = shard * L.shard_cap + base + n0 + (uint32_t)__popcll(r.m1 & lt);
 }
 
 __device__ __forceinline__ uint32_t my_shard() { return (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (NSHARD - 1); }
@@ -161,25 +179,116 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
     }
 }
 
-// ---- shade (optionally fused with trace and, at level 0, with raygen): reference src/tracer.rs:494-583 ----------
-// `level` is this level's index l; the children go to Lnext (level l+1).  At l >= 1 a leaf stores its radiance
-// straight into its parent's val slot; at l == 0 it keeps it in its own coef for the resolve step.
-// At the last traced level (children have depth 0) a child whose terminal light sample needs no shadow ray
-// (reference src/tracer.rs:472-476: Plane::sample said None, or there are no lights) is worth zero, which is
-// written into this node's val slot at once instead of queueing a record for k_terminal.
-template <bool FUSED, bool RAYGEN>
+// ---- shade: reference src/tracer.rs:494-583 ----------------------------------------------------------------------
+// One record of level `level`: material switch, node coefficients, children appended to Lnext (level + 1).
+// At level >= 1 a leaf stores its radiance straight into its parent's val slot; at level 0 it keeps it in its own
+// coef for the resolve step.  At the last traced level (children have depth 0) a child whose terminal light sample
+// needs no shadow ray (reference src/tracer.rs:472-476: Plane::sample said None, or there are no lights) is worth
+// zero, which is written into this node's val slot at once instead of queueing a record for k_terminal.
+// Every lane of the wave must call this (the append uses wave-wide ballots); `valid` masks padding lanes.
+__device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L, const Level &Lprev, const Level &Lnext, uint32_t level,
+                                             uint32_t last_traced, uint32_t shard, bool valid, uint32_t i, V3 o, V3 d, uint32_t skey,
+                                             uint32_t node, uint32_t prim, Counters *ctr
+#ifdef PT_STAMPS
+                                             , unsigned long long *stamp_acc, unsigned long long &stamp_last
+#endif
+                                             ) {
+    // Phase 1: what the hit is and how many children it spawns -- enough to reserve queue space.  The returning
+    // atomic of wave_append is issued before the expensive arithmetic of phase 2 and is only waited for when the
+    // children are written, so its latency (~1-3 us under load) hides under the shading math.
+    ShadeCtx c;
+    c.n_children = 0;
+    const uint32_t nkey = rng_node_key(skey, node);
+    uint32_t par = 0;
+    if (valid) {
+        if (level != 0) par = L.parent[i];
+        shade_prepare(sc, o, d, prim, nkey, c);
+    }
+    bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
+    if (last_traced) {
+        V3 dir, rad;
+        float dist;
+        if (has0 && !terminal_sample(sc, c.o0, rng_node_key(skey, 2u * node), dir, dist, rad)) {
+            L.val0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            has0 = false;
+        }
+        if (has1 && !terminal_sample(sc, c.o1, rng_node_key(skey, 2u * node + 1u), dir, dist, rad)) {
+            L.val1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            has1 = false;
+        }
+    }
+    PT_STAMP(2);  // hit rebuild, material fetch, arm decision, terminal culling
+    Reservation rsv = wave_reserve(Lnext, shard, has0, has1);
+    PT_STAMP(3);  // the append atomic (diagnostic builds wait for it here)
+    // Phase 2: directions and coefficients (no loads in here: a wait for a later load would also wait for the atomic)
+    NodeOut out;
+    if (valid) {
+        shade_finish(c, d, nkey, out);
+        if (out.kind == NK_LEAF) {
+            if (level == 0) {
+                L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
+            } else {
+                float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
+                if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+            }
+        } else {
+            L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.coef_w);
+        }
+        L.meta[i] = out.kind;
+    }
+    PT_STAMP(4);  // sampling / BRDF arithmetic + node stores
+    uint32_t i0, i1;
+    wave_resolve(Lnext, shard, rsv, has0, has1, i0, i1, ctr);
+    PT_STAMP(5);
+    if (has0) {
+        Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
+        Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
+        Lnext.parent[i0] = (i << 1);
+    }
+    if (has1) {
+        Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
+        Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
+        Lnext.parent[i1] = (i << 1) | 1u;
+    }
+}
+
+// Small scenes keep their primitive and material tables in LDS for the shading step: there every lane fetches the
+// rows of the primitive IT hit (a divergent gather: two dependent round trips to the vector cache per record when
+// read from global memory; ~64-cycle LDS reads instead).  The intersection loop keeps its scalar loads: it reads
+// the same row in all lanes.
+constexpr int LDS_SCENE_CAP = 1024;  // float4 rows: n_sph + 4 n_pl + 2 (n_sph + n_pl) must fit (16 KiB)
+__host__ __device__ inline bool lds_scene_fits(uint32_t n_sph, uint32_t n_pl) { return 3ull * n_sph + 6ull * n_pl <= LDS_SCENE_CAP; }
+
+// Wave-granular kernel: each wave takes 64 consecutive records.  FUSED: intersection here as well; RAYGEN: level 0
+// generates its primary rays in place; LDS_SCENE: see above (the host checks lds_scene_fits).
+template <bool FUSED, bool RAYGEN, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
+    __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
+    DevScene lsc = sc;  // what the shading step reads
+    if (LDS_SCENE) {
+        const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 2u * (sc.n_sph + sc.n_pl);
+        for (uint32_t j = threadIdx.x; j < n_s; j += BLOCK) s_scene[j] = sc.sph[j];
+        for (uint32_t j = threadIdx.x; j < n_p; j += BLOCK) s_scene[n_s + j] = sc.pln[j];
+        for (uint32_t j = threadIdx.x; j < n_m; j += BLOCK) s_scene[n_s + n_p + j] = sc.mat[j];
+        __syncthreads();
+        lsc.sph = s_scene;
+        lsc.pln = s_scene + n_s;
+        lsc.mat = s_scene + n_s + n_p;
+    }
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();
+#ifdef PT_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         bool valid = tile_record(m, L, w, i);
-        NodeOut out;
-        out.n_children = 0;
-        uint32_t skey = 0, node = 0;
+        V3 o = v3(0.f, 0.f, 0.f), d = o;
+        uint32_t skey = 0, node = 0, prim = MISS;
         if (valid) {
-            V3 o, d;
             if (RAYGEN) {
                 primary_ray(sc, pp, i, o, d, skey);
                 node = 1u;
@@ -189,48 +298,107 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
                 skey = f2u(b.z);
                 node = f2u(b.w);
             }
-            uint32_t prim;
+        }
+        PT_STAMP(0);  // tile bookkeeping + ray fetch
+        if (valid) {
             if (FUSED) { float t; prim = nearest_hit(sc, o, d, t); }
             else prim = L.hitprim[i];
-            shade_hit(sc, o, d, prim, rng_node_key(skey, node), out);
-            if (out.kind == NK_LEAF) {
-                if (level == 0) {
-                    L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
-                } else {
-                    uint32_t par = L.parent[i];
-                    float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
-                    if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
-                }
+        }
+        PT_STAMP(1);  // intersection
+#ifdef PT_STAMPS
+        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, ctr, stamp_acc, stamp_last);
+#else
+        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, ctr);
+#endif
+        PT_STAMP(6);  // child stores
+    }
+#ifdef PT_STAMPS
+    if (lane_id() == 0) for (int k = 0; k < 8; ++k) if (stamp_acc[k]) atomicAdd(&ctr->stamps[k], stamp_acc[k]);
+#endif
+}
+
+// Block-granular kernel: the 256 records a block takes per step are intersected first, then REGROUPED through LDS
+// by the match arm they will take (shade_class), so that three of the block's four waves typically run one arm of
+// the material switch instead of all of them (the arms differ by hundreds of instructions: GGX + Cook-Torrance vs
+// cosine sampling vs refraction).  A stable counting sort over 6 classes: per-wave ballots -> 4x6 counts in LDS ->
+// every lane derives its slot.  Records carry their own index, so which lane shades a record is irrelevant.
+constexpr int NCLASS = 6;  // diffuse, specular, glass, mirror, leaf, padding
+__device__ __forceinline__ uint32_t class_slot(uint32_t nk) {
+    return nk == NK_DIFFUSE ? 0u : nk == NK_SPECULAR ? 1u : nk == NK_GLASS ? 2u : nk == NK_MIRROR ? 3u : 4u;
+}
+
+template <bool RAYGEN>
+__global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp,
+                                                                      uint32_t level, uint32_t last_traced, Counters *ctr) {
+    __shared__ float4 s_a[BLOCK], s_b[BLOCK];
+    __shared__ uint2 s_c[BLOCK];
+    __shared__ uint32_t s_cnt[BLOCK / 64][8];
+    TileMap m = tile_map(L);
+    const uint32_t shard = my_shard();
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_steps = (m.total + (BLOCK / 64) - 1) / (BLOCK / 64);
+    for (uint32_t step = blockIdx.x; step < n_steps; step += gridDim.x) {
+        const uint32_t w = step * (BLOCK / 64) + wave;
+        uint32_t i = 0;
+        bool valid = false;
+        if (w < m.total) valid = tile_record(m, L, w, i);
+        V3 o = v3(0.f, 0.f, 0.f), d = o;
+        uint32_t skey = 0, node = 0, prim = MISS, cls = NCLASS - 1;
+        if (valid) {
+            if (RAYGEN) {
+                primary_ray(sc, pp, i, o, d, skey);
+                node = 1u;
             } else {
-                L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.coef_w);
+                float4 a = L.rayA[i], b = L.rayB[i];
+                o = v3(a.x, a.y, a.z); d = v3(a.w, b.x, b.y);
+                skey = f2u(b.z);
+                node = f2u(b.w);
             }
-            L.meta[i] = out.kind;
+            float t;
+            prim = nearest_hit(sc, o, d, t);
+            cls = class_slot(shade_class(sc, prim, rng_node_key(skey, node)));
         }
-        bool has0 = valid && out.n_children >= 1, has1 = valid && out.n_children >= 2;
-        if (last_traced) {
-            V3 dir, rad;
-            float dist;
-            if (has0 && !terminal_sample(sc, out.o0, rng_node_key(skey, 2u * node), dir, dist, rad)) {
-                L.val0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                has0 = false;
+        // ---- counting sort of the block's records by class
+        unsigned long long mk[NCLASS];
+        uint32_t my_count = 0;
+        unsigned long long my_mask = 0;
+#pragma unroll
+        for (int c = 0; c < NCLASS; ++c) {
+            mk[c] = __ballot(cls == (uint32_t)c);
+            if (lane == (uint32_t)c) my_count = (uint32_t)__popcll(mk[c]);
+            if (cls == (uint32_t)c) my_mask = mk[c];
+        }
+        if (lane < NCLASS) s_cnt[wave][lane] = my_count;
+        __syncthreads();
+        uint32_t slot = (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int c = 0; c < NCLASS; ++c) {
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int ww = 0; ww < BLOCK / 64; ++ww) {
+                uint32_t n = s_cnt[ww][c];
+                total += n;
+                if ((uint32_t)ww < wave) before += n;
             }
-            if (has1 && !terminal_sample(sc, out.o1, rng_node_key(skey, 2u * node + 1u), dir, dist, rad)) {
-                L.val1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                has1 = false;
-            }
+            if ((uint32_t)c < cls) slot += total;
+            if ((uint32_t)c == cls) slot += before;
         }
-        uint32_t i0, i1;
-        wave_append(Lnext, shard, has0, has1, i0, i1, ctr);
-        if (has0) {
-            Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
-            Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
-            Lnext.parent[i0] = (i << 1);
-        }
-        if (has1) {
-            Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
-            Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
-            Lnext.parent[i1] = (i << 1) | 1u;
-        }
+        s_a[slot] = make_float4(o.x, o.y, o.z, d.x);
+        s_b[slot] = make_float4(d.y, d.z, u2f(skey), u2f(node));
+        s_c[slot] = make_uint2(prim, valid ? i : 0xFFFFFFFFu);
+        __syncthreads();
+        float4 a = s_a[threadIdx.x], b = s_b[threadIdx.x];
+        uint2 c2 = s_c[threadIdx.x];
+        __syncthreads();  // everyone has its record before the next step overwrites the staging arrays
+        bool v2 = c2.y != 0xFFFFFFFFu;
+#ifdef PT_STAMPS
+        unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+        shade_record(sc, L, Lprev, Lnext, level, last_traced, shard, v2, c2.y, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), f2u(b.z), f2u(b.w),
+                     c2.x, ctr, stamp_acc, stamp_last);
+#else
+        shade_record(sc, L, Lprev, Lnext, level, last_traced, shard, v2, c2.y, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), f2u(b.z), f2u(b.w),
+                     c2.x, ctr);
+#endif
     }
 }
 

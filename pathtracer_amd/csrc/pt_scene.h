@@ -232,78 +232,132 @@ struct NodeOut {
 
 PT_HD V3 sky_radiance(const DevScene &sc, V3 direction);
 
-PT_HD void shade_hit(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, uint32_t node_key, NodeOut &out) {
-    out.n_children = 0;
-    out.coef_w = 0.0f;
-    out.kind = NK_LEAF;
+// shade_hit is split in two so a kernel can learn how many child rays a hit spawns (and where they start) before
+// paying for the sampling/BRDF arithmetic:
+//   shade_prepare : rebuild the Hit of the nearest primitive, fetch its material, decide the match arm
+//                   (reference src/tracer.rs:501-569; for Physically the arm depends on the node's third and fourth
+//                   draws only: `random32() < f0[xorshift32() % 3]`, :549) and the child origins (:496-497)
+//   shade_finish  : the arm's arithmetic -- child directions and node coefficients
+struct ShadeCtx {
     Hit hit;
-    if (prim == MISS || !prim_hit(sc, prim, origin, direction, hit)) {  // :571-583
-        out.coef = sky_radiance(sc, direction);
+    float4 m0, m1;     // material rows
+    V3 f0;             // Physically: mix(0.04, reflectivity, metalness)
+    uint32_t kind;     // NK_* arm
+    int n_children;
+    V3 o0, o1;         // child origins (o1: glass reflection)
+    V3 leaf;           // NK_LEAF: the radiance
+};
+
+
+PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, uint32_t node_key, ShadeCtx &c) {
+    c.n_children = 0;
+    c.kind = NK_LEAF;
+    if (prim == MISS || !prim_hit(sc, prim, origin, direction, c.hit)) {  // :571-583
+        c.leaf = sky_radiance(sc, direction);
         return;
     }
     const float SHIFT_AMOUNT = 0.0001f;  // :495
     const float R = 0.04f;               // :499
-    float4 m0 = sc.mat[2 * prim], m1 = sc.mat[2 * prim + 1];
-    uint32_t kind = f2u(m0.x);
-    V3 color = v3(m0.y, m0.z, m0.w);
-    V3 outwards = hit.position + SHIFT_AMOUNT * hit.normal;
-    switch (kind) {
-    case MAT_NONE:  // :502
-        out.coef = v3(1.0f, 1.0f, 1.0f);
+    c.m0 = sc.mat[2 * prim];
+    c.m1 = sc.mat[2 * prim + 1];
+    uint32_t mat = f2u(c.m0.x);
+    V3 color = v3(c.m0.y, c.m0.z, c.m0.w);
+    V3 outwards = c.hit.position + SHIFT_AMOUNT * c.hit.normal;
+    c.o0 = outwards;
+    switch (mat) {
+    case MAT_NONE: c.leaf = v3(1.0f, 1.0f, 1.0f); return;   // :502
+    case MAT_EMISSIVE: c.leaf = color; return;               // :503-505
+    case MAT_MIRROR: c.kind = NK_MIRROR; c.n_children = 1; return;  // :506-510
+    case MAT_TRANSLUCENT:                                    // :511-536
+        c.kind = NK_GLASS;
+        c.n_children = 2;
+        c.o0 = c.hit.position - SHIFT_AMOUNT * c.hit.normal;
+        c.o1 = outwards;
         return;
-    case MAT_EMISSIVE:  // :503-505
-        out.coef = color;
-        return;
-    case MAT_MIRROR: {  // :506-510
-        out.kind = NK_MIRROR;
-        out.coef = v3(0.0f, 0.0f, 0.0f);
-        out.n_children = 1;
-        out.o0 = outwards;
-        out.d0 = normalize(reflect(direction, hit.normal));
+    default: {                                               // MAT_PHYSICALLY, :537-569
+        float metalness = c.m1.y;
+        c.f0 = (1.0f - metalness) * v3(R, R, R) + metalness * color;  // mix_vec3, src/common.rs:68-70
+        float a = random32(rng_draw(node_key, 2));
+        uint32_t ch = rng_draw(node_key, 3) % 3u;
+        float f0c = ch == 0 ? c.f0.x : (ch == 1 ? c.f0.y : c.f0.z);
+        c.kind = a < f0c ? NK_SPECULAR : NK_DIFFUSE;
+        c.n_children = 1;
         return;
     }
-    case MAT_TRANSLUCENT: {  // :511-536
-        float ior = m1.z;
+    }
+}
+
+PT_HD void shade_finish(const ShadeCtx &c, V3 direction, uint32_t node_key, NodeOut &out) {
+    const float R = 0.04f;
+    out.kind = c.kind;
+    out.n_children = c.n_children;
+    out.coef_w = 0.0f;
+    out.o0 = c.o0;
+    out.o1 = c.o1;
+    const Hit &hit = c.hit;
+    switch (c.kind) {
+    case NK_LEAF:
+        out.coef = c.leaf;
+        return;
+    case NK_MIRROR:
+        out.coef = v3(0.0f, 0.0f, 0.0f);
+        out.d0 = normalize(reflect(direction, hit.normal));
+        return;
+    case NK_GLASS: {
+        float ior = c.m1.z;
         float n1 = hit.transition == 0 ? 1.0f : ior;
         float n2 = hit.transition == 0 ? ior : 1.0f;
-        out.kind = NK_GLASS;
-        out.n_children = 2;
-        out.o0 = hit.position - SHIFT_AMOUNT * hit.normal;
         out.d0 = normalize(refract(direction, hit.normal, n1, n2));
-        out.o1 = outwards;
         out.d1 = normalize(reflect(direction, hit.normal));
         float cos_theta = max_rs(0.0f, dot(hit.normal, -direction));
         out.coef = fresnel_schlick(cos_theta, v3(R, R, R));
         return;
     }
-    default: {  // MAT_PHYSICALLY, :537-569
-        float roughness = m1.x, metalness = m1.y;
+    default: {
+        float roughness = c.m1.x;
+        V3 color = v3(c.m0.y, c.m0.z, c.m0.w);
         Basis ts = construct_coordinate_system(hit.normal);
-        V3 view = -direction;
-        V3 f0 = (1.0f - metalness) * v3(R, R, R) + metalness * color;  // mix_vec3, src/common.rs:68-70
         float xi_x = random32(rng_draw(node_key, 0));
         float xi_y = random32(rng_draw(node_key, 1));
-        float a = random32(rng_draw(node_key, 2));
-        uint32_t ch = rng_draw(node_key, 3) % 3u;
-        float f0c = ch == 0 ? f0.x : (ch == 1 ? f0.y : f0.z);
-        out.n_children = 1;
-        out.o0 = outwards;
-        if (a < f0c) {
+        if (c.kind == NK_SPECULAR) {
+            V3 view = -direction;
             V3 h = to_basis(ts, importance_sample_ggx(xi_x, xi_y, roughness));
             V3 light = reflect(direction, h);
             out.d0 = normalize(light);
-            out.kind = NK_SPECULAR;
-            out.coef = PI_F * brdf_cook_torrance(view, light, hit.normal, roughness, f0);
+            out.coef = PI_F * brdf_cook_torrance(view, light, hit.normal, roughness, c.f0);
         } else {
             V3 light = to_basis(ts, importance_sample_cos(xi_x, xi_y));
             out.d0 = normalize(light);
-            out.kind = NK_DIFFUSE;
             out.coef = PI_F * (color / PI_F);  // PI * brdf_lambert, :334-337,567
             out.coef_w = dot(light, hit.normal);
         }
         return;
     }
     }
+}
+
+// One whole level of trace_radiance for a hit (prepare + finish).
+PT_HD void shade_hit(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, uint32_t node_key, NodeOut &out) {
+    ShadeCtx c;
+    shade_prepare(sc, origin, direction, prim, node_key, c);
+    shade_finish(c, direction, node_key, out);
+}
+
+// The arm a hit will take, without rebuilding the hit (used to regroup rays by arm).
+PT_HD uint32_t shade_class(const DevScene &sc, uint32_t prim, uint32_t node_key) {
+    if (prim == MISS) return NK_LEAF;
+    float4 m0 = sc.mat[2 * prim];
+    uint32_t kind = f2u(m0.x);
+    if (kind == MAT_NONE || kind == MAT_EMISSIVE) return NK_LEAF;
+    if (kind == MAT_MIRROR) return NK_MIRROR;
+    if (kind == MAT_TRANSLUCENT) return NK_GLASS;
+    const float R = 0.04f;
+    float metalness = sc.mat[2 * prim + 1].y;
+    V3 f0 = (1.0f - metalness) * v3(R, R, R) + metalness * v3(m0.y, m0.z, m0.w);
+    float a = random32(rng_draw(node_key, 2));
+    uint32_t ch = rng_draw(node_key, 3) % 3u;
+    float f0c = ch == 0 ? f0.x : (ch == 1 ? f0.y : f0.z);
+    return a < f0c ? NK_SPECULAR : NK_DIFFUSE;
 }
 
 // Radiance of a node from its coefficients and its children's radiance (the tail of each match arm of

@@ -55,6 +55,8 @@ struct PtHandle {
     uint32_t *d_shard_caps = nullptr;  // [n_levels]
     Counters *d_ctr = nullptr;
     bool fused = true;
+    bool lds_scene = false;       // primitive/material tables fit the shade kernel's LDS copy
+    bool regroup = true;          // fused kernel regroups each block's records by material arm (fuse_trace_shade 2 / auto)
     size_t lds_bytes = 0;
     uint64_t device_bytes = 0;
 
@@ -169,15 +171,16 @@ int alloc_levels(PtHandle *h) {
     const int D = h->cfg.max_depth;
     h->n_levels = D + 1;
     uint32_t branch_cap = h->cfg.branch_capacity ? h->cfg.branch_capacity : 16u;
-    // samples per pixel per pass: about 4M records at level 0, bounded by a memory budget
+    // samples per pixel per pass: about 8M records at level 0 (fewer, larger launches: +5 % over 4M), bounded by a
+    // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
     uint32_t b = h->cfg.samples_per_batch;
-    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (4u << 20) / std::max<uint32_t>(P, 1)));
+    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (8u << 20) / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
     const uint64_t rec_bytes = 16 + 16 + 4 + 4 + 4 + 16 + 16 + 16;
-    const uint64_t budget = 24ull << 30;
+    const uint64_t budget = 48ull << 30;
     for (;;) {
         uint64_t total = 0;
         for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4;
@@ -225,7 +228,14 @@ int alloc_levels(PtHandle *h) {
     return PT_OK;
 }
 
-constexpr int GRID_TILES = 2048;  // persistent blocks of the tile kernels: 256 CUs x 8
+// Blocks of the tile kernels (grid-stride over wave-tiles).  Measured on the 1080p sample scene: 2048 blocks (all
+// resident, ~6 tiles per wave) is 7 % slower than 8192 (1-2 tiles per wave, the dispatcher balances uneven tiles);
+// beyond 16k the empty blocks start to cost.  PTGPU_GRID overrides it (tuning only).
+static int grid_tiles() {
+    static int g = [] { const char *e = getenv("PTGPU_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8192; }();
+    return g;
+}
+#define GRID_TILES grid_tiles()
 
 int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
     const uint32_t P = h->sc.width * h->sc.height;
@@ -252,15 +262,26 @@ int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
         const uint32_t last = (l == D - 1) ? 1u : 0u;
         if (h->fused) {
             Span s(h, PT_KERNEL_TRACE_SHADE);
-            if (l == 0) k_shade<true, true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-            else k_shade<true, false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            if (h->regroup) {
+                if (l == 0) k_shade_sorted<true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                else k_shade_sorted<false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            } else {
+                if (h->lds_scene) {
+                    if (l == 0) k_shade<true, true, true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                } else {
+                    if (l == 0) k_shade<true, true, false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                }
+            }
         } else {
             {
                 Span s(h, PT_KERNEL_TRACE);
                 k_trace<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L);
             }
             Span s(h, PT_KERNEL_SHADE);
-            k_shade<false, false><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            if (h->lds_scene) k_shade<false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            else k_shade<false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         }
     }
     {
@@ -463,6 +484,8 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
         h->lds_bytes = (size_t)BVH_STACK * BVH_STACK_STRIDE * 4;
     }
     h->fused = h->cfg.fuse_trace_shade != 0;
+    h->lds_scene = lds_scene_fits(sc.n_sph, sc.n_pl);
+    h->regroup = h->cfg.fuse_trace_shade < 0 || h->cfg.fuse_trace_shade >= 2;
 
     // ---- accumulators and queues
     const size_t P = (size_t)s->width * s->height;
@@ -610,6 +633,7 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         HIPCHK(h, hipMemcpy(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost));
         out->rays = c.rays + c.shadow;
         out->shadow_rays = c.shadow;
+        for (int k = 0; k < 8; ++k) out->debug_cycles[k] = c.stamps[k];
         out->records = c.records;
         out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
     }
