@@ -105,8 +105,10 @@ typedef struct {
     uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records; 0 = 16 */
     int32_t accel;                /* PT_ACCEL_* */
     int32_t fuse_trace_shade;     /* 0: trace and shade kernels; 1: one fused kernel per level; 2: fused, and each block regroups
-                                     its rays by material arm before shading; -1: auto (= 2) */
+                                     its rays by material arm before shading; -1: auto (BVH scenes 0, others 1) */
     int32_t profile_events;       /* 1: bracket kernels with HIP events and report per-kernel time in PtStats */
+    uint32_t concurrent_passes;   /* 1..4 pipeline passes in flight (own queues and HIP stream each; one fills the GPU while
+                                     another drains its last long rays); 0 = auto (2 for BVH scenes, else 1) */
 } PtConfig;
 
 enum { PT_KERNEL_RAYGEN = 0, PT_KERNEL_TRACE = 1, PT_KERNEL_SHADE = 2, PT_KERNEL_TRACE_SHADE = 3,
@@ -163,7 +165,10 @@ int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples);
  * the caller provides (width*height*3 u32 words, on this handle's device). */
 int ptgpu_export_pixels32(PtHandle *h, void *dst_device);
 int ptgpu_import_pixels32(PtHandle *h, const void *src_device, uint64_t num_samples);
-/* The hipStream_t all work of this handle is enqueued on (as void*), for event timing by the caller. */
+/* The handle's hipStream_t (as void*), for event timing by the caller.  Everything a call of this library enqueues is
+ * ordered on this stream by the time the call returns (a second, internal stream that carries every other pass is
+ * joined into it at the end of ptgpu_render); work the caller enqueues here itself is not seen by that second stream
+ * until ptgpu_sync. */
 int ptgpu_stream(PtHandle *h, void **stream);
 
 int ptgpu_get_stats(PtHandle *h, PtStats *out);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "pt_bvh.h"
@@ -25,7 +26,8 @@ namespace pt {
 
 struct BvhBuilder {
     std::vector<BvhNode> nodes;
-    std::vector<uint32_t> prims;   // leaf primitive ids
+    std::vector<uint32_t> prims;   // leaf primitive ids, in leaf order
+    std::vector<float4> geom;      // the same primitives' geometry, 4 vectors each, id in the last word (device bvh_geom)
     std::vector<uint32_t> always;  // primitives tested for every ray
     int max_depth_seen = 0;
 
@@ -48,12 +50,15 @@ struct BvhBuilder {
     std::vector<uint32_t> idx;
     std::vector<BuildNode> bn;
     double pad = 0.0;
+    const std::vector<float4> *src_sph = nullptr, *src_pln = nullptr;
 
     static bool finite3(double a, double b, double c) { return std::isfinite(a) && std::isfinite(b) && std::isfinite(c); }
 
     void build(const std::vector<float4> &sph, const std::vector<float4> &pln, V3 cam_pos, V3 cam_plane_origin) {
         const uint32_t n_sph = (uint32_t)sph.size(), n_pl = (uint32_t)(pln.size() / 4);
         const uint32_t n = n_sph + n_pl;
+        src_sph = &sph; src_pln = &pln;
+        geom.clear();
         pbox.resize(n);
         pcent.resize(3 * (size_t)n);
         idx.clear();
@@ -204,6 +209,14 @@ struct BvhBuilder {
             std::vector<uint32_t> ids(idx.begin() + n.first, idx.begin() + n.first + n.count);
             std::sort(ids.begin(), ids.end());
             prims.insert(prims.end(), ids.begin(), ids.end());
+            const uint32_t n_sph = (uint32_t)src_sph->size();
+            for (uint32_t id : ids) {
+                float4 q[4] = {};
+                if (id < n_sph) q[0] = (*src_sph)[id];
+                else for (int k = 0; k < 4; ++k) q[k] = (*src_pln)[4 * (size_t)(id - n_sph) + k];
+                std::memcpy(&q[3].w, &id, 4);
+                geom.insert(geom.end(), q, q + 4);
+            }
             return ~(int32_t)((first << 3) | (n.count - 1));
         }
         return inner_index[b];
@@ -212,12 +225,14 @@ struct BvhBuilder {
     void set_box(BvhNode &N, int which, const Box &b) {
         float lo[3], hi[3];
         for (int d = 0; d < 3; ++d) { lo[d] = down(b.lo[d] - pad); hi[d] = up(b.hi[d] + pad); }
-        if (which == 0) { N.a = make_float4(lo[0], lo[1], lo[2], hi[0]); N.b.x = hi[1]; N.b.y = hi[2]; }
-        else { N.b.z = lo[0]; N.b.w = lo[1]; N.c = make_float4(lo[2], hi[0], hi[1], hi[2]); }
+        float *f = &N.a.x;  // 12 floats: (lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) of child 0 in the even slots, child 1 in the odd ones
+        for (int d = 0; d < 3; ++d) { f[2 * d + which] = lo[d]; f[6 + 2 * d + which] = hi[d]; }
     }
 
     void flatten() {
-        // inner build nodes get device node indices in breadth-first order, so the top of the tree is contiguous
+        // Inner build nodes get device node indices in depth-first preorder: a node's first child is the next
+        // 64 bytes, a subtree is one contiguous run, and - leaves being emitted in the same order - so is its
+        // geometry; rays that are close in space then share cache lines on the way down.
         std::vector<int32_t> inner_index(bn.size(), -1), order;
         if (bn[0].left < 0) {  // a single leaf: wrap it in a root
             BvhNode root{};
@@ -228,12 +243,14 @@ struct BvhBuilder {
             nodes.push_back(root);
             return;
         }
-        order.push_back(0);
-        inner_index[0] = 0;
-        for (size_t k = 0; k < order.size(); ++k) {
-            const BuildNode &n = bn[order[k]];
-            for (int32_t c : {n.left, n.right})
-                if (bn[c].left >= 0) { inner_index[c] = (int32_t)order.size(); order.push_back(c); }
+        std::vector<int32_t> todo{0};
+        while (!todo.empty()) {
+            int32_t b = todo.back();
+            todo.pop_back();
+            inner_index[b] = (int32_t)order.size();
+            order.push_back(b);
+            if (bn[bn[b].right].left >= 0) todo.push_back(bn[b].right);
+            if (bn[bn[b].left].left >= 0) todo.push_back(bn[b].left);
         }
         nodes.resize(order.size());
         for (size_t k = 0; k < order.size(); ++k) {

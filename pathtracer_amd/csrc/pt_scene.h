@@ -37,7 +37,8 @@ struct DevScene {
     const float4 *lights;    // [n_es] radiance of emissive spheres, then [n_ep * 4] emissive planes:
                              //   (origin.xyz, n.x) (n.yz, u.xy) (u.z, v.xyz) (radiance.xyz, 0)
     const BvhNode *bvh_nodes;   // null: linear scan
-    const uint32_t *bvh_prims;  // primitive ids referenced by BVH leaves, ascending inside a leaf
+    const float4 *bvh_geom;     // [leaf prims * 4] primitives in leaf order: the plane's 4 vectors (or the sphere's one), id in the last word
+    uint2 *bvh_spill;           // traversal stack entries beyond the LDS part (see pt_bvh.h)
     const uint32_t *bvh_always; // primitives that cannot be bounded: tested for every ray
     uint32_t n_always;
     // camera (reference src/tracer.rs:104-111: per-pixel step vectors of CameraSampler)

@@ -23,10 +23,24 @@ struct EventSpan { int kernel; hipEvent_t start, stop; };
 
 }  // namespace
 
+// What one pipeline pass owns: its queues, counters, stream and (BVH scenes) traversal spill area.  Passes on
+// different pipes overlap on the GPU; only the accumulation into the pixel sums is ordered between them.
+constexpr int PT_MAX_PIPES = 4;
+struct Pipe {
+    hipStream_t stream = nullptr;      // pipe 0 uses the handle's stream
+    hipEvent_t resolved = nullptr;     // recorded after the pass has added its samples to the accumulator
+    bool resolved_pending = false;
+    std::vector<Level> levels;
+    std::vector<void *> level_allocs;
+    uint32_t *d_counts = nullptr;      // [(n_levels + 1) * NSHARD * CSTRIDE]: per level, then the shadow-ray row
+    uint2 *d_bvh_spill = nullptr;
+    DevScene sc{};                     // the handle's scene with this pipe's spill area
+};
+
 struct PtHandle {
     PtConfig cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // what the caller sees: everything a call enqueues is ordered on it when the call returns
     std::string error;
 
     bool have_scene = false;
@@ -35,7 +49,8 @@ struct PtHandle {
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
     float *d_sky = nullptr, *d_gamma = nullptr;
     BvhNode *d_bvh_nodes = nullptr;
-    uint32_t *d_bvh_prims = nullptr, *d_bvh_always = nullptr;
+    float4 *d_bvh_geom = nullptr;
+    uint32_t *d_bvh_always = nullptr;
     uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
     bool has_glass = false;
 
@@ -46,12 +61,12 @@ struct PtHandle {
     uint64_t num_samples = 0;      // what pixels8 divides by (global count after a multi-GPU combine)
     uint64_t local_samples = 0;    // samples per pixel this handle rendered since clear
 
-    // queues
+    // queues: one set per pass in flight
     int n_levels = 0;              // max_depth + 1
     uint32_t batch = 0;            // samples per pixel per pass
-    std::vector<Level> levels;
-    std::vector<void *> level_allocs;
-    uint32_t *d_counts = nullptr;      // [(n_levels + 1) * NSHARD * CSTRIDE]: per level, then the shadow-ray row
+    int n_pipes = 0;
+    uint64_t passes = 0;           // passes launched since the scene was uploaded (pass k runs on pipe k % n_pipes)
+    Pipe pipes[PT_MAX_PIPES];
     uint32_t *d_shard_caps = nullptr;  // [n_levels]
     Counters *d_ctr = nullptr;
     bool fused = true;
@@ -99,12 +114,16 @@ void dev_free(T *&p) {
 
 void free_scene(PtHandle *h) {
     dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
-    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_prims); dev_free(h->d_bvh_always);
+    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always);
     dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
-    for (void *p : h->level_allocs) (void)hipFree(p);
-    h->level_allocs.clear();
-    h->levels.clear();
-    dev_free(h->d_counts); dev_free(h->d_shard_caps); dev_free(h->d_ctr);
+    for (Pipe &p : h->pipes) {
+        for (void *a : p.level_allocs) (void)hipFree(a);
+        p.level_allocs.clear();
+        p.levels.clear();
+        dev_free(p.d_counts); dev_free(p.d_bvh_spill);
+        p.resolved_pending = false;
+    }
+    dev_free(h->d_shard_caps); dev_free(h->d_ctr);
     h->have_scene = false;
     h->device_bytes = 0;
 }
@@ -133,12 +152,12 @@ hipEvent_t get_event(PtHandle *h) {
 }
 
 struct Span {
-    PtHandle *h; int k; hipEvent_t a = nullptr, b = nullptr;
-    Span(PtHandle *h_, int k_) : h(h_), k(k_) {
-        if (h->cfg.profile_events) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+    PtHandle *h; int k; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Span(PtHandle *h_, int k_, hipStream_t st_) : h(h_), k(k_), st(st_) {
+        if (h->cfg.profile_events) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
     }
     ~Span() {
-        if (h->cfg.profile_events) { (void)hipEventRecord(b, h->stream); h->spans.push_back({k, a, b}); }
+        if (h->cfg.profile_events) { (void)hipEventRecord(b, st); h->spans.push_back({k, a, b}); }
     }
 };
 
@@ -162,9 +181,17 @@ __global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t sha
     uint32_t c = 0;
     if (start < n_records) c = (uint32_t)std::min<uint64_t>(shard_cap, n_records - start);
     count0[q * CSTRIDE] = c;
+    if (q == 0) count0[1] = 0;  // work counter of the dynamic-fetch trace kernel
 }
 
 uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
+
+// auto: two passes in flight for BVH scenes (measured on the 1M-rectangle field: +50 % at 8 spp per pass); the fused
+// kernels of small scenes have no long tail to hide and gain nothing from a second pass (16.1 vs 15.9 Grays/s)
+int pipes_wanted(const PtHandle *h) {
+    const uint32_t c = h->cfg.concurrent_passes;
+    return c == 0 ? (h->sc.bvh_nodes ? 2 : 1) : (int)std::min<uint32_t>(c, PT_MAX_PIPES);
+}
 
 int alloc_levels(PtHandle *h) {
     const uint32_t P = h->sc.width * h->sc.height;
@@ -174,7 +201,9 @@ int alloc_levels(PtHandle *h) {
     // samples per pixel per pass: about 8M records at level 0 (fewer, larger launches: +5 % over 4M), bounded by a
     // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
     uint32_t b = h->cfg.samples_per_batch;
-    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (8u << 20) / std::max<uint32_t>(P, 1)));
+    // (BVH scenes: 16M - a launch ends with a few rays that walk hundreds of nodes, and longer launches dilute that)
+    const uint64_t target = h->sc.bvh_nodes ? (16u << 20) : (8u << 20);
+    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
@@ -183,46 +212,56 @@ int alloc_levels(PtHandle *h) {
     const uint64_t budget = 48ull << 30;
     for (;;) {
         uint64_t total = 0;
-        for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4;
+        for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4 * pipes_wanted(h);
         if (total <= budget || b == 1 || h->cfg.samples_per_batch != 0) break;
         b = std::max<uint32_t>(1, b / 2);
     }
     h->batch = b;
     const uint64_t S = (uint64_t)P * b;
     std::vector<uint32_t> caps(h->n_levels);
-    h->levels.resize(h->n_levels);
     int rc;
-    if ((rc = dev_alloc(h, &h->d_counts, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE))) return rc;
     if ((rc = dev_alloc(h, &h->d_shard_caps, (size_t)h->n_levels))) return rc;
     if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
-    for (int l = 0; l <= D; ++l) {
-        uint64_t recs = S * factor(l);
-        uint64_t per = (recs + NSHARD - 1) / NSHARD;
-        uint32_t cap = (l == 0) ? round_up(per, 64) : round_up(per + per / 4 + 128, 64);
-        if ((uint64_t)cap * NSHARD >= (1ull << 31))
-            return fail(h, PT_ERR_INVALID_ARGUMENT, "queue level too large for 31-bit record indices; lower samples_per_batch");
-        caps[l] = cap;
-        size_t n = (size_t)cap * NSHARD;
-        Level &L = h->levels[l];
-        L.shard_cap = cap;
-        L.count = h->d_counts + (size_t)l * NSHARD * CSTRIDE;
-        // one allocation per level, carved into the SoA arrays (16-byte arrays first)
-        size_t bytes = n * rec_bytes;
-        char *base = nullptr;
-        HIPCHK(h, hipMalloc((void **)&base, bytes));
-        h->device_bytes += bytes;
-        h->level_allocs.push_back(base);
-        L.rayA = (float4 *)base; base += n * 16;
-        L.rayB = (float4 *)base; base += n * 16;
-        L.coef = (float4 *)base; base += n * 16;
-        L.val0 = (float4 *)base; base += n * 16;
-        L.val1 = (float4 *)base; base += n * 16;
-        L.parent = (uint32_t *)base; base += n * 4;
-        L.hitprim = (uint32_t *)base; base += n * 4;
-        L.meta = (uint32_t *)base;
+    h->n_pipes = pipes_wanted(h);
+    h->passes = 0;
+    for (int q = 0; q < h->n_pipes; ++q) {
+        Pipe &pipe = h->pipes[q];
+        pipe.levels.resize(h->n_levels);
+        if ((rc = dev_alloc(h, &pipe.d_counts, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE))) return rc;
+        HIPCHK(h, hipMemsetAsync(pipe.d_counts, 0, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE * 4, h->stream));
+        pipe.sc = h->sc;
+        if (h->sc.bvh_nodes) {
+            if ((rc = dev_alloc(h, &pipe.d_bvh_spill, (size_t)(BVH_STACK - BVH_LDS_ENTRIES) * BVH_TRAV_BLOCKS * BVH_STACK_STRIDE))) return rc;
+            pipe.sc.bvh_spill = pipe.d_bvh_spill;
+        }
+        for (int l = 0; l <= D; ++l) {
+            uint64_t recs = S * factor(l);
+            uint64_t per = (recs + NSHARD - 1) / NSHARD;
+            uint32_t cap = (l == 0) ? round_up(per, 64) : round_up(per + per / 4 + 128, 64);
+            if ((uint64_t)cap * NSHARD >= (1ull << 31))
+                return fail(h, PT_ERR_INVALID_ARGUMENT, "queue level too large for 31-bit record indices; lower samples_per_batch");
+            caps[l] = cap;
+            size_t n = (size_t)cap * NSHARD;
+            Level &L = pipe.levels[l];
+            L.shard_cap = cap;
+            L.count = pipe.d_counts + (size_t)l * NSHARD * CSTRIDE;
+            // one allocation per level, carved into the SoA arrays (16-byte arrays first)
+            size_t bytes = n * rec_bytes;
+            char *base = nullptr;
+            HIPCHK(h, hipMalloc((void **)&base, bytes));
+            h->device_bytes += bytes;
+            pipe.level_allocs.push_back(base);
+            L.rayA = (float4 *)base; base += n * 16;
+            L.rayB = (float4 *)base; base += n * 16;
+            L.coef = (float4 *)base; base += n * 16;
+            L.val0 = (float4 *)base; base += n * 16;
+            L.val1 = (float4 *)base; base += n * 16;
+            L.parent = (uint32_t *)base; base += n * 4;
+            L.hitprim = (uint32_t *)base; base += n * 4;
+            L.meta = (uint32_t *)base;
+        }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_shard_caps, caps.data(), caps.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PT_OK;
@@ -237,68 +276,85 @@ static int grid_tiles() {
 }
 #define GRID_TILES grid_tiles()
 
-int run_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
+int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_first) {
     const uint32_t P = h->sc.width * h->sc.height;
+    const DevScene &sc = pipe.sc;
+    std::vector<Level> &levels = pipe.levels;
     const uint32_t S = P * spp;
     const int D = h->cfg.max_depth;
     PassParams pp;
     pp.n_pixels = P;
     pp.sample_stride = h->cfg.shard_count;
     pp.sample_first = h->cfg.shard_index + local_first * h->cfg.shard_count;
-    hipStream_t st = h->stream;
+    hipStream_t st = pipe.stream;
     const uint32_t flat_grid = (uint32_t)std::min<uint64_t>(8192, (S + BLOCK - 1) / BLOCK);
     const size_t lds = h->lds_bytes;
+    // kernels that walk the BVH index a per-thread spill area sized for BVH_TRAV_BLOCKS blocks
+    const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
-    HIPCHK(h, hipMemsetAsync(h->d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 1) * NSHARD * CSTRIDE * 4, st));  // levels 1..D + shadow row
-    k_set_counts0<<<1, NSHARD, 0, st>>>(h->levels[0].count, S, h->levels[0].shard_cap);
+    HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 1) * NSHARD * CSTRIDE * 4, st));  // levels 1..D + shadow row
+    k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap);
     if (!h->fused) {
-        Span s(h, PT_KERNEL_RAYGEN);
-        k_raygen<<<flat_grid, BLOCK, 0, st>>>(h->sc, h->levels[0], pp, S);
+        Span s(h, PT_KERNEL_RAYGEN, st);
+        k_raygen<<<flat_grid, BLOCK, 0, st>>>(sc, levels[0], pp, S);
     }
     for (int l = 0; l < D; ++l) {
-        Level &L = h->levels[l];
-        Level &Lp = h->levels[l > 0 ? l - 1 : 0];
-        Level &Ln = h->levels[l + 1];
+        Level &L = levels[l];
+        Level &Lp = levels[l > 0 ? l - 1 : 0];
+        Level &Ln = levels[l + 1];
         const uint32_t last = (l == D - 1) ? 1u : 0u;
         if (h->fused) {
-            Span s(h, PT_KERNEL_TRACE_SHADE);
+            Span s(h, PT_KERNEL_TRACE_SHADE, st);
             if (h->regroup) {
-                if (l == 0) k_shade_sorted<true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-                else k_shade_sorted<false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                if (l == 0) k_shade_sorted<true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                else k_shade_sorted<false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
             } else {
                 if (h->lds_scene) {
-                    if (l == 0) k_shade<true, true, true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-                    else k_shade<true, false, true><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                    if (l == 0) k_shade<true, true, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
                 } else {
-                    if (l == 0) k_shade<true, true, false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-                    else k_shade<true, false, false><<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                    if (l == 0) k_shade<true, true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
                 }
             }
         } else {
             {
-                Span s(h, PT_KERNEL_TRACE);
-                k_trace<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, L);
+                Span s(h, PT_KERNEL_TRACE, st);
+                if (sc.bvh_nodes) k_trace_dyn<<<TG, BLOCK, lds, st>>>(sc, L, h->d_ctr);
+                else k_trace<<<TG, BLOCK, lds, st>>>(sc, L);
             }
-            Span s(h, PT_KERNEL_SHADE);
-            if (h->lds_scene) k_shade<false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
-            else k_shade<false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(h->sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            Span s(h, PT_KERNEL_SHADE, st);
+            if (h->lds_scene) k_shade<false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            else k_shade<false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         }
     }
     {
-        Span s(h, PT_KERNEL_TERMINAL);
-        k_terminal<<<GRID_TILES, BLOCK, lds, st>>>(h->sc, h->levels[D], h->levels[D - 1],
-                                                   h->d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE);
+        Span s(h, PT_KERNEL_TERMINAL, st);
+        k_terminal<<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1],
+                                                   pipe.d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE);
     }
     for (int l = D - 1; l >= 1; --l) {
-        Span s(h, PT_KERNEL_GATHER);
-        k_gather<<<GRID_TILES, BLOCK, 0, st>>>(h->levels[l], h->levels[l - 1]);
+        Span s(h, PT_KERNEL_GATHER, st);
+        k_gather<<<GRID_TILES, BLOCK, 0, st>>>(levels[l], levels[l - 1]);
     }
+    // The accumulator is read-modify-written without atomics: passes add their samples one after the other.
+    if (other && other->resolved_pending) HIPCHK(h, hipStreamWaitEvent(st, other->resolved, 0));
     {
-        Span s(h, PT_KERNEL_RESOLVE);
-        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(h->sc, h->levels[0], pp, spp, h->d_pixels32);
+        Span s(h, PT_KERNEL_RESOLVE, st);
+        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], pp, spp, h->d_pixels32);
     }
-    k_account<<<1, 64, 0, st>>>(h->d_counts, h->d_shard_caps, h->n_levels, h->d_ctr);
+    k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->d_ctr);
     HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(pipe.resolved, st));
+    pipe.resolved_pending = true;
+    return PT_OK;
+}
+
+int sync_pipes(PtHandle *h) {
+    for (Pipe &p : h->pipes) {
+        if (p.stream) HIPCHK(h, hipStreamSynchronize(p.stream));
+        p.resolved_pending = false;
+    }
     return PT_OK;
 }
 
@@ -348,6 +404,11 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
     h->cfg = *cfg;
     h->device = cfg->device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PT_ERR_HIP; }
+    h->pipes[0].stream = h->stream;
+    bool ok = true;
+    for (int q = 1; q < PT_MAX_PIPES; ++q) ok = ok && hipStreamCreateWithFlags(&h->pipes[q].stream, hipStreamNonBlocking) == hipSuccess;
+    for (Pipe &p : h->pipes) ok = ok && hipEventCreateWithFlags(&p.resolved, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ptgpu_destroy(h); return PT_ERR_HIP; }
     *out = h;
     return PT_OK;
 }
@@ -355,8 +416,10 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
 void ptgpu_destroy(PtHandle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (Pipe &p : h->pipes) if (p.stream) (void)hipStreamSynchronize(p.stream);
     free_scene(h);
+    for (Pipe &p : h->pipes) if (p.resolved) (void)hipEventDestroy(p.resolved);
+    for (int q = 1; q < PT_MAX_PIPES; ++q) if (h->pipes[q].stream) (void)hipStreamDestroy(h->pipes[q].stream);
     for (auto &s : h->spans) { (void)hipEventDestroy(s.start); (void)hipEventDestroy(s.stop); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -471,21 +534,22 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
         BvhBuilder builder;
         builder.build(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
         if ((rc = dev_alloc(h, &h->d_bvh_nodes, builder.nodes.size()))) return rc;
-        if ((rc = dev_alloc(h, &h->d_bvh_prims, std::max<size_t>(1, builder.prims.size())))) return rc;
+        if ((rc = dev_alloc(h, &h->d_bvh_geom, std::max<size_t>(4, builder.geom.size())))) return rc;
         HIPCHK(h, hipMemcpy(h->d_bvh_nodes, builder.nodes.data(), builder.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
-        if (!builder.prims.empty())
-            HIPCHK(h, hipMemcpy(h->d_bvh_prims, builder.prims.data(), builder.prims.size() * 4, hipMemcpyHostToDevice));
+        if (!builder.geom.empty())
+            HIPCHK(h, hipMemcpy(h->d_bvh_geom, builder.geom.data(), builder.geom.size() * sizeof(float4), hipMemcpyHostToDevice));
         if ((rc = dev_alloc(h, &h->d_bvh_always, std::max<size_t>(1, builder.always.size())))) return rc;
         if (!builder.always.empty())
             HIPCHK(h, hipMemcpy(h->d_bvh_always, builder.always.data(), builder.always.size() * 4, hipMemcpyHostToDevice));
-        sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_prims = h->d_bvh_prims;
+        sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_geom = h->d_bvh_geom;  // (the spill area belongs to the pipes)
         sc.bvh_always = h->d_bvh_always; sc.n_always = (uint32_t)builder.always.size();
         h->bvh_nodes = builder.nodes.size(); h->bvh_leaf_prims = builder.prims.size();
-        h->lds_bytes = (size_t)BVH_STACK * BVH_STACK_STRIDE * 4;
+        h->lds_bytes = (size_t)BVH_LDS_ENTRIES * BVH_STACK_STRIDE * sizeof(uint2);
     }
-    h->fused = h->cfg.fuse_trace_shade != 0;
+    // auto: BVH scenes run intersection as its own kernel (dynamic ray fetch), small scenes fuse it with shading
+    h->fused = h->cfg.fuse_trace_shade < 0 ? (sc.bvh_nodes == nullptr) : (h->cfg.fuse_trace_shade != 0);
     h->lds_scene = lds_scene_fits(sc.n_sph, sc.n_pl);
-    h->regroup = h->cfg.fuse_trace_shade < 0 || h->cfg.fuse_trace_shade >= 2;
+    h->regroup = h->cfg.fuse_trace_shade >= 2;  // measured no faster than the plain fused kernel: opt-in only
 
     // ---- accumulators and queues
     const size_t P = (size_t)s->width * s->height;
@@ -519,26 +583,35 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
+    // Calls that touch the accumulator (clear, import, upload) finish on the host before they return, so the second
+    // pipe needs no edge from the handle's stream; successive render calls overlap like the passes of one call.
     uint32_t done = 0;
     while (done < n_samples) {
         uint32_t spp = std::min(h->batch, n_samples - done);
-        int rc = run_pass(h, spp, (uint32_t)h->local_samples);
+        Pipe &pipe = h->pipes[h->passes % h->n_pipes];
+        Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;  // the pass before this one
+        int rc = run_pass(h, pipe, other, spp, (uint32_t)h->local_samples);
         if (rc) return rc;
+        ++h->passes;
         done += spp;
         h->local_samples += spp;
         h->num_samples += spp;
         if (h->cfg.profile_events && h->spans.size() > 4096) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if ((rc = sync_pipes(h))) return rc;
             if ((rc = drain_spans(h))) return rc;
         }
     }
+    // join: later work on the handle's stream is ordered after both pipes
+    for (int q = 1; q < h->n_pipes; ++q)
+        if (h->pipes[q].resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->pipes[q].resolved, 0));
     return PT_OK;
 }
 
 int ptgpu_sync(PtHandle *h) {
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc0 = sync_pipes(h);
+    if (rc0) return rc0;
     int rc = drain_spans(h);
     if (rc) return rc;
     if (h->have_scene) return check_overflow(h);
@@ -575,7 +648,7 @@ int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out) 
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     const uint32_t n = h->sc.width * h->sc.height;
-    k_primary_ids<<<std::min<uint32_t>(8192, (n + BLOCK - 1) / BLOCK), BLOCK, h->lds_bytes, h->stream>>>(h->sc, sample_index, h->d_ids);
+    k_primary_ids<<<std::min<uint32_t>(BVH_TRAV_BLOCKS, (n + BLOCK - 1) / BLOCK), BLOCK, h->lds_bytes, h->stream>>>(h->pipes[0].sc, sample_index, h->d_ids);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, h->d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
