@@ -73,3 +73,54 @@ def test_unboundable_and_dead_planes(binding, oracle):
     ids_l, p_l, _ = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 2)
     assert np.array_equal(ids_b[0], ids_l[0]) and np.array_equal(p_b, p_l)
     assert np.array_equal(ids_b[0], oracle.OracleScene(sc).primary_ids(oracle.options(), 0))
+
+
+def test_deep_traversal_stack_spills_correctly(binding):
+    """16384 small spheres zig-zag along the view axis: a central ray misses every sphere but pierces every box,
+    so the traversal stack grows to the depth of the tree (about 12), beyond the part that is kept in LDS, and the
+    entries that spill to global memory must come back intact.  Several passes run concurrently on their own
+    streams, each with its own spill area."""
+    n, r = 16384, 0.05
+    sc = S.Scene(image_settings=S.ImageSettings(48, 36, True),
+                 camera=S.Camera((0.0, 0.0, 40.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.012, 0.009, 20.0, S.TONE_CLAMP, 1.0, 100.0),
+                 sky=S.Sky.constant((0.6, 0.7, 0.8)))
+    k = np.arange(n)
+    spheres = np.zeros(n, dtype=S.SPHERE_DT)
+    spheres["radius"] = r
+    spheres["origin"] = np.stack([np.where(k % 2 == 0, 2.0 * r, -2.0 * r), np.zeros(n), 10.0 - k * 0.01], axis=1).astype(np.float32)
+    spheres["material"]["kind"] = S.MAT_PHYSICALLY
+    spheres["material"]["color"] = (0.8, 0.5, 0.3)
+    spheres["material"]["roughness"] = 0.6
+    spheres["material"]["ior"] = 1.0
+    sc.spheres = spheres
+    sc.add(S.Plane((-30.0, -30.0, -160.0), (60.0, 0.0, 0.0), (0.0, 60.0, 0.0), S.Material.physically((0.7, 0.7, 0.7), 0.8, 0.0)))
+    sc.add(S.Plane((-4.0, 6.0, -60.0), (8.0, 0.0, 0.0), (0.0, 0.0, 40.0), S.Material.emissive((9.0, 9.0, 9.0))))
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 6, samples_per_batch=1, concurrent_passes=3)
+    ids_l, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 6)
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_b, p_l) and st_b["rays"] == st_l["rays"]
+    centre = ids_b[0].reshape(36, 48)[16:20, 22:26]
+    assert np.all(centre == n)  # the central rays thread the whole row and end on the back plane
+    assert len(np.unique(ids_b[0])) > 50
+
+
+@pytest.mark.parametrize("pipes", [1, 2, 4])
+def test_concurrent_passes_sum_to_the_same_image(binding, oracle, pipes):
+    """Passes in flight on separate streams add into one integer accumulator: any number of them, any pass size,
+    gives the sums of a single pass (and of the oracle)."""
+    sc = materials_scene(96, 72)
+    with binding.PtGpu(samples_per_batch=2, concurrent_passes=pipes) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(5)
+        gpu.render(4)
+        p32, n = gpu.read_pixels32()
+        rays = gpu.stats()["rays"]
+        gpu.clear()
+        gpu.render(3)
+        q32, m = gpu.read_pixels32()
+    assert n == 9 and m == 3
+    osc = oracle.OracleScene(sc)
+    r32, _, r_rays = osc.render(oracle.options(), 9)
+    assert np.array_equal(p32, r32) and rays == r_rays
+    assert np.array_equal(q32, osc.render(oracle.options(), 3)[0])
