@@ -157,7 +157,9 @@ def main() -> None:
                 # write kind 4 + coef-or-leaf-value 16; per appended child: write ray 32 + parent 4
                 alg = 52.0 * traced - 32.0 * st["samples"] + 36.0 * children
             elif name == "trace":
-                alg = 36.0 * traced                           # read ray 32, write prim id 4
+                # read ray 32, write prim id 4; BVH: one 64-byte fetch per traversal step (inner node or leaf
+                # primitive), counted by the kernel itself (deterministic per ray, independent of scheduling)
+                alg = 36.0 * traced + 64.0 * st["bvh_steps"]
             elif name == "shade":
                 alg = 56.0 * traced + 36.0 * children
             else:
@@ -182,7 +184,8 @@ def main() -> None:
                 "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
             }
         if st["bvh_nodes"]:
-            out["bvh"] = {"nodes": st["bvh_nodes"], "leaf_prims": st["bvh_leaf_prims"]}
+            out["bvh"] = {"nodes": st["bvh_nodes"], "leaf_prims": st["bvh_leaf_prims"],
+                          "steps_per_traced_ray": round(st["bvh_steps"] / max(1, st["rays"] - st["shadow_rays"]), 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_seconds, 8)
         print(json.dumps(out), flush=True)

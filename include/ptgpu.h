@@ -120,6 +120,7 @@ typedef struct {
     uint64_t shadow_rays;                     /* the part of `rays` traced by terminal light samples */
     uint64_t records;                         /* queue records processed over all levels since clear */
     uint64_t bvh_nodes, bvh_leaf_prims;       /* size of the current BVH (0 for brute force) */
+    uint64_t bvh_steps;                       /* 64-byte fetches (inner nodes + leaf primitives) made by the BVH trace kernel since clear */
     uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */
     double kernel_ms[PT_KERNEL_COUNT];        /* since clear (profile_events only) */
     uint64_t device_bytes;                    /* device memory held by the handle */

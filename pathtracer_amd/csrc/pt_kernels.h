@@ -56,7 +56,7 @@ struct PassParams {
 };
 
 // device-side counters (one allocation)
-struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow; unsigned long long stamps[8]; };
+struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow, bvh_steps; unsigned long long stamps[8]; };
 
 // Diagnostic builds (-DPT_STAMPS) time the phases of the fused kernel with s_memtime; never part of a shipped build.
 #ifdef PT_STAMPS
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
     bool exhausted = false, active = false;
     Trav st;
     st.node = BVH_EMPTY;
+    uint32_t my_steps = 0;  // 64-byte fetches (inner nodes + leaf primitives) this lane made: the kernel's algorithmic traffic
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if (idle != 0 && next >= end && !exhausted) {  // chunk used up: claim the next one (one atomic per wave and chunk)
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
                 if (st.node < 0) ++n_leaf;
 #endif
                 bvh_step(sc, st, stk);
+                ++my_steps;
                 if (st.node == BVH_EMPTY) {
                     L.hitprim[rec] = st.best;
                     active = false;
@@ -267,6 +269,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
 #endif
         }
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_steps += __shfl_xor(my_steps, o);
+    if (lane_id() == 0 && my_steps) atomicAdd(&ctr->bvh_steps, (unsigned long long)my_steps);
 #ifdef PT_TRAV_STATS
     atomicAdd(&ctr->stamps[0], n_steps); atomicAdd(&ctr->stamps[1], n_slots); atomicAdd(&ctr->stamps[2], n_leaf); atomicMax(&ctr->stamps[3], max_steps > ray_steps ? max_steps : ray_steps);
 #endif

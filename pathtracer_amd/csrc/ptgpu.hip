@@ -708,6 +708,7 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         out->shadow_rays = c.shadow;
         for (int k = 0; k < 8; ++k) out->debug_cycles[k] = c.stamps[k];
         out->records = c.records;
+        out->bvh_steps = c.bvh_steps;
         out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
     }
     out->bvh_nodes = h->bvh_nodes;
