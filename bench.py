@@ -170,7 +170,7 @@ def main() -> None:
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(name)
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
                 except Exception:
                     traffic = None
             out["roofline"] = {
