@@ -143,9 +143,14 @@ __device__ __forceinline__ uint32_t sample_key_of(const DevScene &sc, const Pass
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef const f4_t __attribute__((address_space(4))) *const_f4_ptr;
 
+// `transition`: the winner's Transition when the search knows it (linear scan), -1 when it does not (BVH).
+__device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t, int &transition) {
+    if (sc.bvh_nodes) { transition = -1; return bvh_nearest(sc, o, d, t); }
+    return nearest_brute((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
+}
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t) {
-    if (sc.bvh_nodes) return bvh_nearest(sc, o, d, t);
-    return nearest_brute((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t);
+    int transition;
+    return nearest_hit(sc, o, d, t, transition);
 }
 
 // ---- raygen: reference src/tracer.rs:125-142,628-631 -------------------------------------------------------
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
 // Every lane of the wave must call this (the append uses wave-wide ballots); `valid` masks padding lanes.
 __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L, const Level &Lprev, const Level &Lnext, uint32_t level,
                                              uint32_t last_traced, uint32_t shard, bool valid, uint32_t i, V3 o, V3 d, uint32_t skey,
-                                             uint32_t node, uint32_t prim, Counters *ctr
+                                             uint32_t node, uint32_t prim, float hit_t, int hit_transition, Counters *ctr
 #ifdef PT_STAMPS
                                              , unsigned long long *stamp_acc, unsigned long long &stamp_last
 #endif
@@ -302,7 +307,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
     uint32_t par = 0;
     if (valid) {
         if (level != 0) par = L.parent[i];
-        shade_prepare(sc, o, d, prim, nkey, c);
+        shade_prepare(sc, o, d, prim, hit_t, hit_transition, nkey, c);
     }
     bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
     if (last_traced) {
@@ -388,6 +393,8 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
         bool valid = tile_record(m, L, w, i);
         V3 o = v3(0.f, 0.f, 0.f), d = o;
         uint32_t skey = 0, node = 0, prim = MISS;
+        float hit_t = 0.0f;
+        int hit_tr = -1;
         if (valid) {
             if (RAYGEN) {
                 primary_ray(sc, pp, i, o, d, skey);
@@ -401,14 +408,14 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
         }
         PT_STAMP(0);  // tile bookkeeping + ray fetch
         if (valid) {
-            if (FUSED) { float t; prim = nearest_hit(sc, o, d, t); }
+            if (FUSED) prim = nearest_hit(sc, o, d, hit_t, hit_tr);
             else prim = L.hitprim[i];
         }
         PT_STAMP(1);  // intersection
 #ifdef PT_STAMPS
-        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, ctr, stamp_acc, stamp_last);
+        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr, stamp_acc, stamp_last);
 #else
-        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, ctr);
+        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr);
 #endif
         PT_STAMP(6);  // child stores
     }
@@ -494,10 +501,10 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene
 #ifdef PT_STAMPS
         unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
         shade_record(sc, L, Lprev, Lnext, level, last_traced, shard, v2, c2.y, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), f2u(b.z), f2u(b.w),
-                     c2.x, ctr, stamp_acc, stamp_last);
+                     c2.x, 0.0f, -1, ctr, stamp_acc, stamp_last);
 #else
         shade_record(sc, L, Lprev, Lnext, level, last_traced, shard, v2, c2.y, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), f2u(b.z), f2u(b.w),
-                     c2.x, ctr);
+                     c2.x, 0.0f, -1, ctr);
 #endif
     }
 }

@@ -56,8 +56,9 @@ struct Hit { float t; V3 position; V3 normal; int transition; };  // transition 
 
 // ---- spheres: reference src/scene.rs:169-221 ---------------------------------------------------------
 // Accept/reject and distance only (what the nearest-hit search needs).
+// `out` = 1 when the accepted root is the far one (Transition::Out: the ray starts inside the sphere).
 template <class T4>
-PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t) {
+PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t, int &out) {
     V3 s = v3(sp.x, sp.y, sp.z);
     float r = sp.w;
     V3 c = s - p;
@@ -76,10 +77,12 @@ PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t) {
     float b = sqrt_ieee(r2 - v_len * v_len);
     float t1 = e_len - b;
     float t2 = e_len + b;
-    if (t1 >= 0.0f) { t = t1; return true; }
-    if (t2 >= 0.0f) { t = t2; return true; }
+    if (t1 >= 0.0f) { t = t1; out = 0; return true; }
+    if (t2 >= 0.0f) { t = t2; out = 1; return true; }
     return false;
 }
+template <class T4>
+PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t) { int out; return sphere_test(sp, p, d, t, out); }
 // Full hit record of a sphere already known to be hit.
 PT_HD bool sphere_hit(float4 sp, V3 p, V3 d, Hit &h) {
     V3 s = v3(sp.x, sp.y, sp.z);
@@ -137,19 +140,21 @@ PT_HD bool plane_test(T4 q0, T4 q1, T4 q2, T4 q3, V3 p, V3 d, float &t, V3 &posi
 // vector (the kernels pass constant-address-space pointers so the wave-uniform primitive fetches become
 // scalar loads into SGPRs).
 template <class P4>
-PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p, V3 d, float &best_t) {
+PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p, V3 d, float &best_t, int &best_out) {
     uint32_t best = MISS;
     best_t = 0.0f;
+    best_out = 0;  // Transition of the winner (planes are only ever accepted as In)
     for (uint32_t i = 0; i < n_sph; ++i) {
         float t;
-        if (sphere_test(sph[i], p, d, t)) {
-            if (best == MISS || t < best_t) { best = i; best_t = t; }
+        int out;
+        if (sphere_test(sph[i], p, d, t, out)) {
+            if (best == MISS || t < best_t) { best = i; best_t = t; best_out = out; }
         }
     }
     for (uint32_t i = 0; i < n_pl; ++i) {
         float t; V3 pos;
         if (plane_test(pln[4 * i], pln[4 * i + 1], pln[4 * i + 2], pln[4 * i + 3], p, d, t, pos)) {
-            if (best == MISS || t < best_t) { best = n_sph + i; best_t = t; }
+            if (best == MISS || t < best_t) { best = n_sph + i; best_t = t; best_out = 0; }
         }
     }
     return best;
@@ -164,6 +169,23 @@ PT_HD bool prim_hit(const DevScene &sc, uint32_t prim, V3 p, V3 d, Hit &h) {
     if (!plane_test(q0, sc.pln[4 * k + 1], sc.pln[4 * k + 2], sc.pln[4 * k + 3], p, d, t, pos)) return false;
     h.t = t; h.position = pos; h.normal = v3(q0.x, q0.y, q0.z); h.transition = 0;
     return true;
+}
+
+// The same Hit from what the nearest-hit search already knows (t and, for spheres, which root): position is the
+// expression both tests use (p + t*d), so only the sphere normal is left to compute.
+PT_HD void prim_hit_known(const DevScene &sc, uint32_t prim, V3 p, V3 d, float t, int transition, Hit &h) {
+    h.t = t;
+    h.position = p + t * d;
+    if (prim < sc.n_sph) {
+        float4 sp = sc.sph[prim];
+        V3 s = v3(sp.x, sp.y, sp.z);
+        h.transition = transition;
+        h.normal = transition == 0 ? normalize(h.position - s) : normalize(s - h.position);
+    } else {
+        float4 q0 = sc.pln[4 * (prim - sc.n_sph)];
+        h.transition = 0;
+        h.normal = v3(q0.x, q0.y, q0.z);
+    }
 }
 
 // ---- optics and BRDFs: reference src/tracer.rs:285-446 ------------------------------------------------
@@ -259,10 +281,17 @@ struct ShadeCtx {
 };
 
 
-PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, uint32_t node_key, ShadeCtx &c) {
+// `transition` < 0: only the primitive id is known, the Hit is rebuilt by re-running its test; otherwise (t,
+// transition) come from the nearest-hit search.
+PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, float t, int transition, uint32_t node_key, ShadeCtx &c) {
     c.n_children = 0;
     c.kind = NK_LEAF;
-    if (prim == MISS || !prim_hit(sc, prim, origin, direction, c.hit)) {  // :571-583
+    bool hit = prim != MISS;
+    if (hit) {
+        if (transition >= 0) prim_hit_known(sc, prim, origin, direction, t, transition, c.hit);
+        else hit = prim_hit(sc, prim, origin, direction, c.hit);
+    }
+    if (!hit) {  // :571-583
         c.leaf = sky_radiance(sc, direction);
         return;
     }
@@ -349,7 +378,7 @@ PT_HD void shade_finish(const ShadeCtx &c, V3 direction, uint32_t node_key, Node
 // One whole level of trace_radiance for a hit (prepare + finish).
 PT_HD void shade_hit(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, uint32_t node_key, NodeOut &out) {
     ShadeCtx c;
-    shade_prepare(sc, origin, direction, prim, node_key, c);
+    shade_prepare(sc, origin, direction, prim, 0.0f, -1, node_key, c);
     shade_finish(c, direction, node_key, out);
 }
 
