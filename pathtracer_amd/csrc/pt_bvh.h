@@ -10,33 +10,33 @@
 //     slab test, a subtree is culled only when its entry distance is strictly beyond the best t, and NaN
 //     slab distances are ignored, so no primitive the linear scan would accept is ever skipped.
 //
-// Node = 64 bytes (half a 128-byte cache line, two nodes per line), holding BOTH children's boxes so one
-// fetch decides both; four 16-byte loads per lane.  Children: >= 0 inner node index, < 0 leaf
-// (~c = first << 3 | count-1 into bvh_geom, ids ascending), BVH_EMPTY = no child.
+// Node = 128 bytes (one cache line): the boxes of up to FOUR children, component-wise (lo.x of all four, lo.y of
+// all four, ...), so one fetch decides four subtrees and the slab tests run as 2-wide packed f32 operations.
+// Children: >= 0 inner node index, < 0 leaf (~c = first << 3 | count-1 into bvh_geom, ids ascending),
+// BVH_EMPTY = no child.  The tree is the binary SAH tree with every other level folded into its parent.
 //
 // Leaf primitives live in their own array in leaf order (bvh_geom, 64 bytes each: the plane's four vectors or the
-// sphere's one, primitive id in the last word), so a leaf test is ONE dependent fetch after the node, with the same
-// shape as a node fetch.  The traversal step below loads 64 bytes from "wherever this lane is" - an inner node or
-// the next primitive of its leaf - and then either descends or tests: every lane of a wave makes progress on every
-// memory round trip, which is what bounds this loop (measured: the texture/L1 path is ~40 % busy, waves wait on the
-// slowest lane's miss; arithmetic is nowhere near a limit).
+// sphere's one, primitive id in the last word), so a leaf test is ONE dependent fetch after the node.  The
+// traversal step below loads up to 128 bytes from "wherever this lane is" - an inner node or the next two
+// primitives of its leaf - and then either descends or tests: every lane of a wave makes progress on every memory
+// round trip, which is what bounds this loop (measured on the 2-wide version: the texture/L1 path ~40 % busy, waves
+// parked on memory 56 % of the time; halving the number of dependent fetches per ray is what the 4-wide node is for).
 #pragma once
 
 #include "pt_scene.h"
 
 namespace pt {
 
-struct BvhNode {   // the two children's boxes interleaved, so both slab tests run as one sequence of 2-wide packed f32 operations
-    float4 a;   // (lo0.x, lo1.x, lo0.y, lo1.y)
-    float4 b;   // (lo0.z, lo1.z, hi0.x, hi1.x)
-    float4 c;   // (hi0.y, hi1.y, hi0.z, hi1.z)
-    int32_t c0, c1;
-    uint32_t pad0, pad1;
+struct BvhNode {
+    float4 lox, loy, loz, hix, hiy, hiz;   // .x = child 0 ... .w = child 3
+    int32_t c[4];
+    uint32_t pad[4];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 
 constexpr int32_t BVH_EMPTY = (int32_t)0x80000000;
-constexpr int BVH_STACK = 40;          // entries per lane; the builder caps the tree depth at this
+constexpr int BVH_BINARY_DEPTH = 38;   // depth cap of the binary tree the builder starts from
+constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 3, the folded tree is at most 20 deep
 #ifndef PT_BVH_LDS_ENTRIES
 #define PT_BVH_LDS_ENTRIES 8
 #endif
@@ -46,19 +46,20 @@ constexpr int BVH_MAX_LEAF = 4;
 constexpr uint32_t BVH_TRAV_BLOCKS = 2048;  // most blocks a traversing kernel is launched with (sizes the spill area)
 
 #if defined(__HIPCC__)
-// Slab test of both children at once.  Distances are lo * inv + (-o * inv) in one fused operation per plane pair
-// (v_pk_fma_f32); against (lo - o) * inv that moves a slab by at most ~|o| * 2^-23, far inside the builder's
-// padding.  NaN distances (inf - inf when the ray is parallel to a slab, 0 * inf) drop out of fminf/fmaxf, which
-// only removes a constraint; tfar is widened by 4 ulp for the rounding of the products.
+// Slab test of two children at once (called twice per node).  Distances are lo * inv + (-o * inv) in one fused
+// operation per plane pair (v_pk_fma_f32); against (lo - o) * inv that moves a slab by at most ~|o| * 2^-23, far
+// inside the builder's padding.  NaN distances (inf - inf when the ray is parallel to a slab, 0 * inf) drop out of
+// fminf/fmaxf, which only removes a constraint; tfar is widened by 4 ulp for the rounding of the products.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 min2(f32x2 x, f32x2 y) { return f32x2{fminf(x.x, y.x), fminf(x.y, y.y)}; }
 __device__ __forceinline__ f32x2 max2(f32x2 x, f32x2 y) { return f32x2{fmaxf(x.x, y.x), fmaxf(x.y, y.y)}; }
-__device__ __forceinline__ void box_entry2(float4 a, float4 b, float4 c, V3 inv, V3 noi, f32x2 &tn, f32x2 &tf) {
+__device__ __forceinline__ void box_entry2(f32x2 lox, f32x2 loy, f32x2 loz, f32x2 hix, f32x2 hiy, f32x2 hiz, V3 inv, V3 noi, f32x2 &tn,
+                                           f32x2 &tf) {
     f32x2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     f32x2 nx = {noi.x, noi.x}, ny = {noi.y, noi.y}, nz = {noi.z, noi.z};
-    f32x2 t0x = __builtin_elementwise_fma(f32x2{a.x, a.y}, ix, nx), t1x = __builtin_elementwise_fma(f32x2{b.z, b.w}, ix, nx);
-    f32x2 t0y = __builtin_elementwise_fma(f32x2{a.z, a.w}, iy, ny), t1y = __builtin_elementwise_fma(f32x2{c.x, c.y}, iy, ny);
-    f32x2 t0z = __builtin_elementwise_fma(f32x2{b.x, b.y}, iz, nz), t1z = __builtin_elementwise_fma(f32x2{c.z, c.w}, iz, nz);
+    f32x2 t0x = __builtin_elementwise_fma(lox, ix, nx), t1x = __builtin_elementwise_fma(hix, ix, nx);
+    f32x2 t0y = __builtin_elementwise_fma(loy, iy, ny), t1y = __builtin_elementwise_fma(hiy, iy, ny);
+    f32x2 t0z = __builtin_elementwise_fma(loz, iz, nz), t1z = __builtin_elementwise_fma(hiz, iz, nz);
     tn = max2(max2(min2(t0x, t1x), min2(t0y, t1y)), max2(min2(t0z, t1z), f32x2{0.0f, 0.0f}));
     tf = min2(min2(max2(t0x, t1x), max2(t0y, t1y)), max2(t0z, t1z)) * 1.0000005f;
 }
@@ -153,43 +154,68 @@ __device__ __forceinline__ void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &
     s.leaf_cur = s.leaf_end = 0;
 }
 
-// One step of an unfinished traversal (s.node != BVH_EMPTY): one 64-byte fetch, then either the two box tests of
-// an inner node (near child next, far child pushed with its entry distance) or one primitive of the current leaf.
-__device__ __forceinline__ void bvh_step(const DevScene &sc, Trav &s, const TravStack &stk) {
+// One primitive record of bvh_geom against the ray.
+__device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, float4 b, float4 c, float4 e, Trav &s) {
+    uint32_t id = __float_as_uint(e.w);
+    float t;
+    bool hit;
+    if (id < sc.n_sph) hit = sphere_test(a, s.o, s.d, t);
+    else { V3 pos; hit = plane_test(a, b, c, e, s.o, s.d, t, pos); }
+    bvh_accept(hit, t, id, s.best, s.best_t);
+}
+
+// One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of up to 128 bytes, then either the four
+// box tests of an inner node (nearest hit child next, the other hit children pushed with their entry distances) or
+// up to two primitives of the current leaf.  Returns the number of 64-byte units it fetched.
+__device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk) {
     const bool in_leaf = s.node < 0;
     const float4 *p = in_leaf ? sc.bvh_geom + 4 * (size_t)s.leaf_cur : reinterpret_cast<const float4 *>(sc.bvh_nodes + s.node);
-    float4 a = p[0], b = p[1], c = p[2], e = p[3];
+    const bool second = !in_leaf || s.leaf_cur + 1u < s.leaf_end;  // an inner node, or a leaf with two primitives left
+    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    float4 q4 = q0, q5 = q0, q6 = q0, q7 = q0;
+    if (second) { q4 = p[4]; q5 = p[5]; q6 = p[6]; if (in_leaf) q7 = p[7]; }
     if (in_leaf) {
-        uint32_t id = __float_as_uint(e.w);
-        float t;
-        bool hit;
-        if (id < sc.n_sph) hit = sphere_test(a, s.o, s.d, t);
-        else { V3 pos; hit = plane_test(a, b, c, e, s.o, s.d, t, pos); }
-        bvh_accept(hit, t, id, s.best, s.best_t);
-        if (++s.leaf_cur == s.leaf_end) trav_pop(s, stk);
-        return;
+        bvh_test_record(sc, q0, q1, q2, q3, s);
+        if (second) bvh_test_record(sc, q4, q5, q6, q7, s);
+        s.leaf_cur += second ? 2u : 1u;
+        if (s.leaf_cur == s.leaf_end) trav_pop(s, stk);
+        return second ? 2u : 1u;
     }
-    int32_t c0 = (int32_t)__float_as_uint(e.x), c1 = (int32_t)__float_as_uint(e.y);
-    f32x2 tn, tf;
-    box_entry2(a, b, c, s.inv, s.noi, tn, tf);
-    const float tn0 = tn.x, tn1 = tn.y;
-    bool h0 = c0 != BVH_EMPTY && tn0 <= tf.x && tn0 <= s.best_t;
-    bool h1 = c1 != BVH_EMPTY && tn1 <= tf.y && tn1 <= s.best_t;
-    if (h0 && h1) {  // depth of the stack is bounded by the builder's depth cap
-        bool first0 = tn0 <= tn1;
-        stk.put(s.sp, make_uint2((uint32_t)(first0 ? c1 : c0), __float_as_uint(first0 ? tn1 : tn0)));
-        ++s.sp;
-        trav_enter(s, first0 ? c0 : c1);
-    } else if (h0) trav_enter(s, c0);
-    else if (h1) trav_enter(s, c1);
-    else trav_pop(s, stk);
+    // q0..q5 = lox, loy, loz, hix, hiy, hiz of the four children; q6 = their references
+    f32x2 tnA, tfA, tnB, tfB;
+    box_entry2(f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, f32x2{q3.x, q3.y}, f32x2{q4.x, q4.y}, f32x2{q5.x, q5.y}, s.inv, s.noi,
+               tnA, tfA);
+    box_entry2(f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, f32x2{q3.z, q3.w}, f32x2{q4.z, q4.w}, f32x2{q5.z, q5.w}, s.inv, s.noi,
+               tnB, tfB);
+    const int32_t c0 = (int32_t)__float_as_uint(q6.x), c1 = (int32_t)__float_as_uint(q6.y);
+    const int32_t c2 = (int32_t)__float_as_uint(q6.z), c3 = (int32_t)__float_as_uint(q6.w);
+    const float INF = __builtin_inff();
+    // key = entry distance of a child the ray must visit, +inf otherwise
+    float k0 = (c0 != BVH_EMPTY && tnA.x <= tfA.x && tnA.x <= s.best_t) ? tnA.x : INF;
+    float k1 = (c1 != BVH_EMPTY && tnA.y <= tfA.y && tnA.y <= s.best_t) ? tnA.y : INF;
+    float k2 = (c2 != BVH_EMPTY && tnB.x <= tfB.x && tnB.x <= s.best_t) ? tnB.x : INF;
+    float k3 = (c3 != BVH_EMPTY && tnB.y <= tfB.y && tnB.y <= s.best_t) ? tnB.y : INF;
+    // (a child entered at distance +inf cannot hold a finite hit, so treating it as missed loses nothing)
+    int j = 0;
+    float kj = k0;
+    if (k1 < kj) { kj = k1; j = 1; }
+    if (k2 < kj) { kj = k2; j = 2; }
+    if (k3 < kj) { kj = k3; j = 3; }
+    if (kj == INF) { trav_pop(s, stk); return 2u; }
+    // the others in fixed order; entries are culled by distance again when they are popped
+    if (j != 3 && k3 < INF) { stk.put(s.sp, make_uint2((uint32_t)c3, __float_as_uint(k3))); ++s.sp; }
+    if (j != 2 && k2 < INF) { stk.put(s.sp, make_uint2((uint32_t)c2, __float_as_uint(k2))); ++s.sp; }
+    if (j != 1 && k1 < INF) { stk.put(s.sp, make_uint2((uint32_t)c1, __float_as_uint(k1))); ++s.sp; }
+    if (j != 0 && k0 < INF) { stk.put(s.sp, make_uint2((uint32_t)c0, __float_as_uint(k0))); ++s.sp; }
+    trav_enter(s, j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3)));
+    return 2u;
 }
 
 __device__ __forceinline__ uint32_t bvh_nearest(const DevScene &sc, V3 o, V3 d, float &best_t) {
     Trav s;
     bvh_begin(sc, o, d, s);
     TravStack stk = trav_stack(sc);
-    while (s.node != BVH_EMPTY) bvh_step(sc, s, stk);
+    while (s.node != BVH_EMPTY) (void)bvh_step(sc, s, stk);
     best_t = s.best_t;
     return s.best;
 }

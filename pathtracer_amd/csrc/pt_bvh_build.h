@@ -115,7 +115,7 @@ struct BvhBuilder {
         bn.clear();
         if (idx.empty()) {  // nothing boundable: a root with two empty children
             BvhNode root{};
-            root.c0 = BVH_EMPTY; root.c1 = BVH_EMPTY;
+            root.c[0] = root.c[1] = root.c[2] = root.c[3] = BVH_EMPTY;
             nodes.push_back(root);
             return;
         }
@@ -139,7 +139,7 @@ struct BvhBuilder {
         if (count <= (uint32_t)BVH_MAX_LEAF) return me;
         // Children sit one level deeper; a leaf holds BVH_MAX_LEAF.  Force a median split when SAH imbalance
         // could otherwise exceed the traversal stack.
-        const int remaining = (BVH_STACK - 2) - depth;
+        const int remaining = BVH_BINARY_DEPTH - depth;
         bool force_median = remaining < 1 || (remaining < 40 && (uint64_t)count > ((uint64_t)BVH_MAX_LEAF << (remaining > 0 ? remaining - 1 : 0)));
         Box cb; cb.reset();
         for (uint32_t i = first; i < first + count; ++i) cb.grow(&pcent[3 * (size_t)idx[i]]);
@@ -223,24 +223,42 @@ struct BvhBuilder {
     }
 
     void set_box(BvhNode &N, int which, const Box &b) {
-        float lo[3], hi[3];
-        for (int d = 0; d < 3; ++d) { lo[d] = down(b.lo[d] - pad); hi[d] = up(b.hi[d] + pad); }
-        float *f = &N.a.x;  // 12 floats: (lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) of child 0 in the even slots, child 1 in the odd ones
-        for (int d = 0; d < 3; ++d) { f[2 * d + which] = lo[d]; f[6 + 2 * d + which] = hi[d]; }
+        float *lo[3] = {&N.lox.x, &N.loy.x, &N.loz.x}, *hi[3] = {&N.hix.x, &N.hiy.x, &N.hiz.x};
+        for (int d = 0; d < 3; ++d) { lo[d][which] = down(b.lo[d] - pad); hi[d][which] = up(b.hi[d] + pad); }
+    }
+
+    // Children of the 4-wide node rooted at binary node b: b's two children, then the inner one with the largest
+    // box is replaced by ITS two children, until there are four or only leaves are left.
+    int fold(int32_t b, int32_t out[4]) const {
+        int n = 0;
+        out[n++] = bn[b].left;
+        out[n++] = bn[b].right;
+        while (n < 4) {
+            int pick = -1;
+            double best = -1.0;
+            for (int k = 0; k < n; ++k)
+                if (bn[out[k]].left >= 0 && bn[out[k]].box.area() > best) { best = bn[out[k]].box.area(); pick = k; }
+            if (pick < 0) break;
+            int32_t c = out[pick];
+            out[pick] = bn[c].left;
+            out[n++] = bn[c].right;
+        }
+        return n;
     }
 
     void flatten() {
-        // Inner build nodes get device node indices in depth-first preorder: a node's first child is the next
-        // 64 bytes, a subtree is one contiguous run, and - leaves being emitted in the same order - so is its
+        // 4-wide nodes get device indices in depth-first preorder: a node's first inner child is the next 128
+        // bytes, a subtree is one contiguous run, and - leaves being emitted in the same order - so is its
         // geometry; rays that are close in space then share cache lines on the way down.
         std::vector<int32_t> inner_index(bn.size(), -1), order;
         if (bn[0].left < 0) {  // a single leaf: wrap it in a root
             BvhNode root{};
             std::vector<int32_t> none;
             set_box(root, 0, bn[0].box);
-            root.c0 = child_ref(0, none);
-            root.c1 = BVH_EMPTY;
+            root.c[0] = child_ref(0, none);
+            root.c[1] = root.c[2] = root.c[3] = BVH_EMPTY;
             nodes.push_back(root);
+            pad_geom();
             return;
         }
         std::vector<int32_t> todo{0};
@@ -249,20 +267,28 @@ struct BvhBuilder {
             todo.pop_back();
             inner_index[b] = (int32_t)order.size();
             order.push_back(b);
-            if (bn[bn[b].right].left >= 0) todo.push_back(bn[b].right);
-            if (bn[bn[b].left].left >= 0) todo.push_back(bn[b].left);
+            int32_t ch[4];
+            int n = fold(b, ch);
+            for (int k = n - 1; k >= 0; --k)
+                if (bn[ch[k]].left >= 0) todo.push_back(ch[k]);
         }
         nodes.resize(order.size());
         for (size_t k = 0; k < order.size(); ++k) {
-            const BuildNode &n = bn[order[k]];
+            int32_t ch[4];
+            int n = fold(order[k], ch);
             BvhNode N{};
-            set_box(N, 0, bn[n.left].box);
-            set_box(N, 1, bn[n.right].box);
-            N.c0 = child_ref(n.left, inner_index);
-            N.c1 = child_ref(n.right, inner_index);
+            for (int j = 0; j < 4; ++j) {
+                if (j < n) { set_box(N, j, bn[ch[j]].box); N.c[j] = child_ref(ch[j], inner_index); }
+                else N.c[j] = BVH_EMPTY;
+            }
             nodes[k] = N;
         }
+        pad_geom();
     }
+
+    // The traversal fetches a leaf's primitives two records at a time but only when two are left, so no read goes
+    // past the array; one spare record keeps that true even if that rule is ever relaxed.
+    void pad_geom() { geom.insert(geom.end(), 4, make_float4(0.f, 0.f, 0.f, 0.f)); }
 };
 
 }  // namespace pt

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
     bool exhausted = false, active = false;
     Trav st;
     st.node = BVH_EMPTY;
-    uint32_t my_steps = 0;  // 64-byte fetches (inner nodes + leaf primitives) this lane made: the kernel's algorithmic traffic
+    uint32_t my_steps = 0;  // 64-byte units (2 per inner node, 1 per leaf primitive) this lane fetched: the kernel's algorithmic traffic
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if (idle != 0 && next >= end && !exhausted) {  // chunk used up: claim the next one (one atomic per wave and chunk)
@@ -264,8 +264,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
                 ++n_steps; ++ray_steps;
                 if (st.node < 0) ++n_leaf;
 #endif
-                bvh_step(sc, st, stk);
-                ++my_steps;
+                my_steps += bvh_step(sc, st, stk);
                 if (st.node == BVH_EMPTY) {
                     L.hitprim[rec] = st.best;
                     active = false;
