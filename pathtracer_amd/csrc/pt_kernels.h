@@ -561,6 +561,13 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
 // One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + pixel) into
 // its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassParams pp, uint32_t spp, uint32_t *pixels32) {
+    // the quantiser's threshold table is searched 24 times per sample with per-lane indices: keep it in LDS
+    __shared__ float s_gamma[256];
+    if (sc.gamma_table != nullptr) {
+        s_gamma[threadIdx.x] = sc.gamma_table[threadIdx.x];
+        __syncthreads();
+        sc.gamma_table = s_gamma;
+    }
     for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < pp.n_pixels; pixel += gridDim.x * BLOCK) {
         uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
 #pragma unroll 2
