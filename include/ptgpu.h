@@ -109,6 +109,10 @@ typedef struct {
     int32_t profile_events;       /* 1: bracket kernels with HIP events and report per-kernel time in PtStats */
     uint32_t concurrent_passes;   /* 1..4 pipeline passes in flight (own queues and HIP stream each; one fills the GPU while
                                      another drains its last long rays); 0 = auto (2 for BVH scenes, else 1) */
+    int32_t camera_model;         /* 0: CameraSampler::pinhole_ray (what the reference renders with, tracer.rs:629);
+                                     1: CameraSampler::thin_lens_ray (tracer.rs:144-197, unused there) */
+    float focus_distance;         /* thin lens: FOCUS_DISTANCE, reference constant 10.0 (tracer.rs:155) */
+    float lens_aperture;          /* thin lens: LENS_APERTURE, reference constant 4.0 (tracer.rs:177); circle of confusion = 22/aperture */
 } PtConfig;
 
 enum { PT_KERNEL_RAYGEN = 0, PT_KERNEL_TRACE = 1, PT_KERNEL_SHADE = 2, PT_KERNEL_TRACE_SHADE = 3,

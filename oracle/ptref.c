@@ -171,6 +171,22 @@ void ptref_pinhole_ray(const pr_scene *scene, const pr_options *opt, uint32_t x,
     *direction = vnormalize(vsub(o, cam->position));
 }
 
+/* tracer.rs:144-197 thin_lens_ray, given the pinhole ray (in/out) and the two random numbers it draws */
+void ptref_thin_lens_ray(const pr_scene *scene, const pr_options *opt, float r1, float r2, pr_vec3 *origin, pr_vec3 *direction) {
+    const pr_camera *cam = &scene->camera;
+    pr_vec3 su = vdivs(cam->plane_u, (float)scene->width);   /* CameraSampler.u / .v, tracer.rs:107-108 */
+    pr_vec3 sv = vdivs(cam->plane_v, (float)scene->height);
+    pr_vec3 point_on_focus_plane = vadd(*origin, vscale(*direction, opt->focus_distance));  /* :160 */
+    float circle_of_confusion = 22.0f / opt->lens_aperture;                                 /* :181 */
+    float alpha = 2.0f * PR_PI * r1;                                                        /* :186 */
+    float r = circle_of_confusion * r2;                                                     /* :187 */
+    float l_u = r * m_sin(opt->math_mode, alpha);                                           /* :189 */
+    float l_v = r * m_cos(opt->math_mode, alpha);                                           /* :190 */
+    pr_vec3 lens_origin = vadd(vadd(*origin, vscale(su, l_u)), vscale(sv, l_v));            /* :192 */
+    *direction = vnormalize(vsub(point_on_focus_plane, lens_origin));                       /* :193 */
+    *origin = lens_origin;
+}
+
 /* ------------------------------------------------------------------------------------------
  * scene.rs: intersection
  * ---------------------------------------------------------------------------------------- */
@@ -577,6 +593,11 @@ static void primary_ray(pr_ctx *c, uint32_t x, uint32_t y, pr_vec3 *o, pr_vec3 *
     float ju = 0.0f, jv = 0.0f;
     if (jitter) { ju = draw_f32(c, 0, 0); jv = draw_f32(c, 0, 1); }
     ptref_pinhole_ray(c->scene, c->opt, x, y, ju, jv, jitter, o, d);
+    if (c->opt->camera_model == 1) {  /* two more draws after the pinhole ray's (tracer.rs:183-184) */
+        float r1 = draw_f32(c, 0, 2);
+        float r2 = draw_f32(c, 0, 3);
+        ptref_thin_lens_ray(c->scene, c->opt, r1, r2, o, d);
+    }
 }
 
 static void render_tile(const pr_scene *scene, const pr_options *opt, pr_backbuffer *bb, uint32_t *xs,

@@ -84,6 +84,9 @@ typedef struct {
     uint32_t seed;            /* PR_RNG_COUNTER key / PR_RNG_XORSHIFT initial state (reference: 314159265) */
     int32_t max_depth;        /* reference: 4 (tracer.rs:633) */
     int32_t sub_pixel_override; /* -1: use scene.sub_pixel_sampling, 0/1: force */
+    int32_t camera_model;     /* 0: pinhole_ray (what render() calls, tracer.rs:629); 1: thin_lens_ray (tracer.rs:144-197) */
+    float focus_distance;     /* thin lens; reference constant 10.0 (tracer.rs:155) */
+    float lens_aperture;      /* thin lens; reference constant 4.0 (tracer.rs:177) */
 } pr_options;
 
 typedef struct {
@@ -124,6 +127,8 @@ void ptref_plane_normals(pr_plane *planes, uint64_t n);
 int32_t ptref_find_scene_hit(const pr_scene *scene, pr_vec3 origin, pr_vec3 direction, pr_hit *out); /* scene.rs:263-297 */
 void ptref_pinhole_ray(const pr_scene *scene, const pr_options *opt, uint32_t x, uint32_t y, float jitter_u,
                        float jitter_v, int32_t jitter, pr_vec3 *origin, pr_vec3 *direction);   /* tracer.rs:125-142 */
+void ptref_thin_lens_ray(const pr_scene *scene, const pr_options *opt, float r1, float r2, pr_vec3 *origin,
+                         pr_vec3 *direction);                                                   /* tracer.rs:144-197 */
 /* radiance of one ray, recursion as tracer.rs:448-584; RNG state as given by opt (xorshift state = *state) */
 pr_vec3 ptref_trace_radiance(const pr_scene *scene, const pr_options *opt, uint32_t *xorshift_state,
                              uint32_t pixel, uint32_t sample, pr_vec3 origin, pr_vec3 direction, int32_t depth,

@@ -49,7 +49,8 @@ class Scene(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("seed", C.c_uint32), ("max_depth", C.c_int32),
-                ("sub_pixel_override", C.c_int32)]
+                ("sub_pixel_override", C.c_int32), ("camera_model", C.c_int32), ("focus_distance", C.c_float),
+                ("lens_aperture", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -101,6 +102,8 @@ def lib() -> C.CDLL:
     L.ptref_pinhole_ray.argtypes = [C.POINTER(Scene), C.POINTER(Options), C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_int32,
                                     C.POINTER(Vec3), C.POINTER(Vec3)]
     L.ptref_pinhole_ray.restype = None
+    L.ptref_thin_lens_ray.argtypes = [C.POINTER(Scene), C.POINTER(Options), C.c_float, C.c_float, C.POINTER(Vec3), C.POINTER(Vec3)]
+    L.ptref_thin_lens_ray.restype = None
     L.ptref_trace_radiance.argtypes = [C.POINTER(Scene), C.POINTER(Options), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, Vec3,
                                        Vec3, C.c_int32, C.POINTER(Stats)]
     L.ptref_trace_radiance.restype = Vec3
@@ -133,8 +136,9 @@ def camera_new(cam) -> Camera:
     return out
 
 
-def options(rng_mode=RNG_COUNTER, math_mode=MATH_DET, seed=314159265, max_depth=4, sub_pixel_override=-1) -> Options:
-    return Options(rng_mode, math_mode, seed, max_depth, sub_pixel_override)
+def options(rng_mode=RNG_COUNTER, math_mode=MATH_DET, seed=314159265, max_depth=4, sub_pixel_override=-1, camera_model=0,
+            focus_distance=10.0, lens_aperture=4.0) -> Options:
+    return Options(rng_mode, math_mode, seed, max_depth, sub_pixel_override, camera_model, focus_distance, lens_aperture)
 
 
 class OracleScene:
@@ -176,6 +180,11 @@ class OracleScene:
         opt = options()
         ju, jv = (jitter if jitter is not None else (0.0, 0.0))
         lib().ptref_pinhole_ray(C.byref(self.desc), C.byref(opt), x, y, ju, jv, 1 if jitter is not None else 0, C.byref(o), C.byref(d))
+        return o.t(), d.t()
+
+    def thin_lens_ray(self, opt: Options, origin, direction, r1, r2):
+        o, d = _v(origin), _v(direction)
+        lib().ptref_thin_lens_ray(C.byref(self.desc), C.byref(opt), r1, r2, C.byref(o), C.byref(d))
         return o.t(), d.t()
 
     def trace_radiance(self, opt: Options, origin, direction, depth=None, pixel=0, sample=0, xorshift_state=314159265):

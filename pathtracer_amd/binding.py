@@ -51,7 +51,8 @@ class PtConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("seed", C.c_uint32), ("max_depth", C.c_int32), ("sub_pixel_override", C.c_int32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("samples_per_batch", C.c_uint32),
                 ("branch_capacity", C.c_uint32), ("accel", C.c_int32), ("fuse_trace_shade", C.c_int32),
-                ("profile_events", C.c_int32), ("concurrent_passes", C.c_uint32)]
+                ("profile_events", C.c_int32), ("concurrent_passes", C.c_uint32), ("camera_model", C.c_int32),
+                ("focus_distance", C.c_float), ("lens_aperture", C.c_float)]
 
 
 class PtStats(C.Structure):

@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, 
 __device__ __forceinline__ void primary_ray(const DevScene &sc, const PassParams &pp, uint32_t sid, V3 &o, V3 &d, uint32_t &skey) {
     uint32_t pixel = sid % pp.n_pixels;
     skey = sample_key_of(sc, pp, sid);
-    pinhole_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
+    camera_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
 }
 
 // Only the two-kernel (trace, shade) pipeline stores primary rays; the fused kernel generates them in place.
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary_ids(DevScene sc, uint32_t sam
     for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < n; pixel += gridDim.x * BLOCK) {
         uint32_t skey = rng_sample_key(sc.seed, pixel, sample_index);
         V3 o, d;
-        pinhole_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
+        camera_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
         float t;
         ids[pixel] = nearest_hit(sc, o, d, t);
     }

@@ -50,6 +50,8 @@ struct DevScene {
     int jitter;
     uint32_t seed;
     int max_depth;
+    int thin_lens;                 // CameraSampler::thin_lens_ray instead of pinhole_ray
+    float focus_distance, circle_of_confusion;
 };
 
 struct Hit { float t; V3 position; V3 normal; int transition; };  // transition 0 = In, 1 = Out
@@ -517,6 +519,26 @@ PT_HD void pinhole_ray(const DevScene &sc, uint32_t x, uint32_t y, uint32_t samp
     V3 dv = offset_v * sc.cam_sv;
     origin = (sc.cam_origin + du) + dv;
     direction = normalize(origin - sc.cam_pos);
+}
+
+// reference src/tracer.rs:144-197 (dead code there; the camera model its TODOs point to).  Two more draws of the
+// camera node after the pinhole ray's.
+PT_HD void camera_ray(const DevScene &sc, uint32_t x, uint32_t y, uint32_t sample_key, V3 &origin, V3 &direction) {
+    pinhole_ray(sc, x, y, sample_key, origin, direction);
+    if (!sc.thin_lens) return;
+    uint32_t cam_key = rng_node_key(sample_key, 0u);
+    V3 point_on_focus_plane = origin + sc.focus_distance * direction;
+    float r1 = random32(rng_draw(cam_key, 2));
+    float r2 = random32(rng_draw(cam_key, 3));
+    float alpha = 2.0f * PI_F * r1;
+    float r = sc.circle_of_confusion * r2;
+    float sa, ca;
+    det::sincosf_(alpha, sa, ca);
+    float l_u = r * sa;
+    float l_v = r * ca;
+    V3 lens_origin = (origin + l_u * sc.cam_su) + l_v * sc.cam_sv;
+    direction = normalize(point_on_focus_plane - lens_origin);
+    origin = lens_origin;
 }
 
 }  // namespace pt

@@ -386,6 +386,10 @@ void ptgpu_default_config(PtConfig *cfg) {
     cfg->accel = PT_ACCEL_AUTO;
     cfg->fuse_trace_shade = -1;
     cfg->profile_events = 0;
+    cfg->concurrent_passes = 0;
+    cfg->camera_model = 0;
+    cfg->focus_distance = 10.0f;  // src/tracer.rs:155
+    cfg->lens_aperture = 4.0f;    // src/tracer.rs:177
 }
 
 int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
@@ -525,6 +529,9 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     sc.jitter = h->cfg.sub_pixel_override < 0 ? (s->sub_pixel_sampling != 0) : (h->cfg.sub_pixel_override != 0);
     sc.seed = h->cfg.seed;
     sc.max_depth = h->cfg.max_depth;
+    sc.thin_lens = h->cfg.camera_model == 1;
+    sc.focus_distance = h->cfg.focus_distance;
+    sc.circle_of_confusion = 22.0f / h->cfg.lens_aperture;  // src/tracer.rs:181
 
     // ---- acceleration structure
     bool want_bvh = h->cfg.accel == PT_ACCEL_BVH || (h->cfg.accel == PT_ACCEL_AUTO && n_sph + n_pl > 48);

@@ -163,4 +163,20 @@ bool write_ppm(const std::string &path, const Backbuffer &bb) {
     return (bool)f;
 }
 
+// Portable float map of the accumulated mean (the value assign_pixel8 scales by iso and clamps, reference
+// src/tracer.rs:271-281: sum / (num_samples * 255)), for offline comparison of renders without the 8-bit step.
+// Little-endian (negative scale), rows bottom to top as the format defines - the backbuffer's own order.
+bool write_pfm(const std::string &path, const Backbuffer &bb) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f || bb.num_samples == 0) return false;
+    f << "PF\n" << bb.width << " " << bb.height << "\n-1.0\n";
+    std::vector<float> row((size_t)bb.width * 3);
+    const float denom = (float)bb.num_samples * 255.0f;
+    for (uint32_t y = 0; y < bb.height; ++y) {
+        for (size_t k = 0; k < row.size(); ++k) row[k] = (float)bb.pixels32[(size_t)y * bb.width * 3 + k] / denom;
+        f.write((const char *)row.data(), (std::streamsize)(row.size() * sizeof(float)));
+    }
+    return (bool)f;
+}
+
 }  // namespace pthost

@@ -154,5 +154,6 @@ private:
 
 // Image export (the reference has none: it only presents to a window).  Rows are flipped so row 0 is the top.
 bool write_ppm(const std::string &path, const Backbuffer &bb);
+bool write_pfm(const std::string &path, const Backbuffer &bb);  // accumulated mean as floats (.pfm)
 
 }  // namespace pthost

@@ -5,7 +5,7 @@
 // restarted (:130-141).  Instead of presenting 1 spp per frame forever it renders `--spp` samples per pixel
 // through libptgpu, prints the frame time the way the reference does (:227-228) and writes a PPM.
 //
-//   ptcli --path=scene.scene --spp=64 --out=image.ppm [--frames=N] [--depth=4] [--device=0] [--reference-comments]
+//   ptcli --path=scene.scene --spp=64 --out=image.ppm [--frames=N] [--depth=4] [--device=0] [--reference-comments] [--thin-lens]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +58,7 @@ int main(int argc, char **argv) {
     ptgpu_default_config(&cfg);
     cfg.device = device;
     cfg.max_depth = depth;
+    if (arg_flag(argc, argv, "--thin-lens")) cfg.camera_model = 1;  // CameraSampler::thin_lens_ray (reference src/tracer.rs:144-197)
     Renderer r;
     int rc = r.create(&cfg);
     if (rc) { std::fprintf(stderr, "ptgpu_create failed (%d): an MI355X (gfx950) is required, there is no CPU path\n", rc); return 2; }
@@ -78,6 +79,7 @@ int main(int argc, char **argv) {
     PtStats st;
     r.stats(st);
     std::printf("%ux%u, %llu spp, %llu rays\n", bb.width, bb.height, (unsigned long long)bb.num_samples, (unsigned long long)st.rays);
-    if (!write_ppm(out_path, bb)) { std::fprintf(stderr, "could not write %s\n", out_path.c_str()); return 5; }
+    const bool pfm = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".pfm") == 0;
+    if (!(pfm ? write_pfm(out_path, bb) : write_ppm(out_path, bb))) { std::fprintf(stderr, "could not write %s\n", out_path.c_str()); return 5; }
     return 0;
 }

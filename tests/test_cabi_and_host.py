@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_header(binding):
     assert C.sizeof(binding.PtVec3) == 12
     assert C.sizeof(binding.PtCamera) == 4 * 12 + 6 * 4
     assert C.sizeof(binding.PtSky) == 40
-    assert C.sizeof(binding.PtConfig) == 12 * 4
+    assert C.sizeof(binding.PtConfig) == 15 * 4
     assert S.MATERIAL_DT.itemsize == 28 and S.SPHERE_DT.itemsize == 44 and S.PLANE_DT.itemsize == 76
     assert C.sizeof(binding.PtSceneDesc) == 12 + C.sizeof(binding.PtCamera) + 4 + C.sizeof(binding.PtSky) + 8 * 8
 

@@ -73,3 +73,22 @@ def test_hdri_sky_through_file_loader(binding, oracle, tmp_path):
     sc.sky.pixels = tex
     _, ref8, _ = oracle.OracleScene(sc).render(oracle.options(), 4)
     assert np.array_equal(img, ref8)
+
+
+def test_ptcli_thin_lens_and_pfm_export(binding, tmp_path):
+    """--thin-lens selects CameraSampler::thin_lens_ray; a .pfm output holds the accumulated mean as floats."""
+    sc = S.sample_scene(64, 48, camera_width=6.6666667)
+    path = str(tmp_path / "s.scene")
+    open(path, "w").write(S.to_text(sc))
+    out = str(tmp_path / "o.pfm")
+    r = subprocess.run([CLI, f"--path={path}", "--spp=3", f"--out={out}", "--thin-lens"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    data = open(out, "rb").read()
+    head, dims, scale, body = data.split(b"\n", 3)
+    assert head == b"PF" and dims == b"64 48" and float(scale) < 0
+    img = np.frombuffer(body, dtype="<f4").reshape(48, 64, 3)
+    with binding.PtGpu(camera_model=1) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(3)
+        p32, n = gpu.read_pixels32()
+    assert np.array_equal(img, p32.reshape(48, 64, 3).astype(np.float32) / np.float32(3 * 255.0))

@@ -259,3 +259,25 @@ def test_glass_queue_overflow_is_detected(binding):
         with pytest.raises(binding.PtGpuError) as e:
             gpu.read_pixels32()
         assert e.value.code == -5
+
+
+def test_thin_lens_camera_bit_exact(binding, oracle):
+    """CameraSampler::thin_lens_ray (reference src/tracer.rs:144-197; dead code there) as an optional camera model:
+    primary-hit ids and accumulated pixels against the oracle, both pipelines."""
+    sc = S.sample_scene(128, 96, camera_width=6.6666667)
+    opt = oracle.options(camera_model=1, focus_distance=12.0, lens_aperture=8.0)
+    osc = oracle.OracleScene(sc)
+    r32, r8, rays = osc.render(opt, 5)
+    for fused in (1, 0):
+        with binding.PtGpu(camera_model=1, focus_distance=12.0, lens_aperture=8.0, fuse_trace_shade=fused) as gpu:
+            gpu.upload_scene(sc)
+            ids = gpu.primary_ids(3)
+            gpu.render(5)
+            p32, _ = gpu.read_pixels32()
+            assert np.array_equal(ids, osc.primary_ids(opt, 3))
+            assert np.array_equal(p32, r32) and gpu.stats()["rays"] == rays
+            assert np.array_equal(gpu.read_pixels8(), r8)
+    with binding.PtGpu() as gpu:  # and it is not the pinhole image
+        gpu.upload_scene(sc)
+        gpu.render(5)
+        assert not np.array_equal(gpu.read_pixels32()[0], r32)

@@ -157,3 +157,45 @@ def test_det_pow_special_cases(oracle):
     assert P(-0.5, 5.0) == -0.03125                    # negative base, odd integer exponent (1 - cos_theta can be < 0)
     assert P(float("inf"), 0.45) == float("inf") and P(-float("inf"), 0.45) == float("inf")
     assert P(-0.0, 0.45) == 0.0 and P(7.0, 0.0) == 1.0
+
+
+def test_thin_lens_ray_follows_the_reference_formula(oracle):
+    # reference src/tracer.rs:144-197, redone here step by step in numpy float32
+    sc = S.sample_scene()
+    osc = oracle.OracleScene(sc)
+    o, d = osc.pinhole_ray(300, 700, jitter=(0.25, 0.75))
+    F = np.float32
+    o32, d32 = np.array(o, dtype=F), np.array(d, dtype=F)
+    cam = osc.desc.camera
+    su = np.array(cam.plane_u.t(), dtype=F) / F(sc.image_settings.width)
+    sv = np.array(cam.plane_v.t(), dtype=F) / F(sc.image_settings.height)
+    for r1, r2 in ((0.5, 1.0), (0.125, 0.3), (1.0, 0.01)):
+        focus = o32 + F(10.0) * d32
+        coc = F(22.0) / F(4.0)
+        alpha = F(2.0) * F(np.pi) * F(r1)
+        r = coc * F(r2)
+        l_u = r * F(math.sin(float(alpha)))
+        l_v = r * F(math.cos(float(alpha)))
+        lens_o = (o32 + l_u * su) + l_v * sv
+        diff = focus - lens_o
+        length = np.sqrt(F((diff[0] * diff[0] + diff[1] * diff[1]) + diff[2] * diff[2]))
+        lens_d = diff / length
+        for mode in (oracle.MATH_LIBM, oracle.MATH_DET):
+            oo, dd = osc.thin_lens_ray(oracle.options(math_mode=mode, camera_model=1), o, d, r1, r2)
+            # sin/cos differ from the double-rounded value by at most an ulp; everything else is exact f32 arithmetic
+            assert np.allclose(oo, lens_o, rtol=0, atol=2e-6) and np.allclose(dd, lens_d, rtol=0, atol=2e-6)
+    # r2 -> 0 collapses the lens to the pinhole origin: the ray is the pinhole ray again
+    oo, dd = osc.thin_lens_ray(oracle.options(camera_model=1), o, d, 0.3, 0.0)
+    assert oo == o and np.allclose(dd, d, atol=1e-7)
+
+
+def test_thin_lens_draws_follow_the_pinhole_draws(oracle):
+    # xorshift stream: u, v jitter first, then r1, r2 (src/tracer.rs:132-133,183-184); with the counter RNG they
+    # are dimensions 2 and 3 of the camera node.  Same scene, same seed: the pinhole image differs from the
+    # thin-lens image, and both are reproducible.
+    sc = S.sample_scene(64, 48, camera_width=6.6666667)
+    osc = oracle.OracleScene(sc)
+    a = osc.primary_ids(oracle.options(camera_model=0), 0)
+    b = osc.primary_ids(oracle.options(camera_model=1), 0)
+    c = osc.primary_ids(oracle.options(camera_model=1), 0)
+    assert np.array_equal(b, c) and not np.array_equal(a, b)
