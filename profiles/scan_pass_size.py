@@ -1,4 +1,9 @@
-import sys, time
+"""Diagnostic: throughput of the quad-field (BVH) workload against samples per pass and passes in flight.
+Run from the repo root on the GPU box: python profiles/scan_pass_size.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time
 from pathtracer_amd import binding as B, scene as S
 sc = S.quad_field_scene(1920, 1080)
 for b, np_ in ((4, 1), (4, 2), (4, 3), (4, 4), (8, 2), (8, 3), (8, 4), (16, 2), (16, 4)):

@@ -1,4 +1,8 @@
-import sys, time
+"""Diagnostic: BVH traversal steps per ray and lane utilisation on the quad field.  Needs a library built with
+-DPT_TRAV_STATS selected through PTGPU_LIB.  Usage: PTGPU_LIB=... python profiles/traversal_stats.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pathtracer_amd import binding as B, scene as S
 sc = S.quad_field_scene(1920, 1080)
 cfg = B.default_config(); cfg.fuse_trace_shade = 0
