@@ -355,20 +355,32 @@ PT_HD void shade_finish(const ShadeCtx &c, V3 direction, uint32_t node_key, Node
         return;
     }
     default: {
+        // Specular (:550-561) and diffuse (:562-568) bounces of one wave run as ONE instruction stream: which random
+        // number feeds the angle, what goes under the two square roots and how the local vector is assembled are
+        // selected per lane, everything else (sin/cos, roots, change of basis, normalisation) is shared.  Every lane
+        // still performs exactly the operations of its own arm (importance_sample_ggx / importance_sample_cos).
+        const bool spec = c.kind == NK_SPECULAR;
         float roughness = c.m1.x;
         V3 color = v3(c.m0.y, c.m0.z, c.m0.w);
         Basis ts = construct_coordinate_system(hit.normal);
         float xi_x = random32(rng_draw(node_key, 0));
         float xi_y = random32(rng_draw(node_key, 1));
-        if (c.kind == NK_SPECULAR) {
-            V3 view = -direction;
-            V3 h = to_basis(ts, importance_sample_ggx(xi_x, xi_y, roughness));
-            V3 light = reflect(direction, h);
-            out.d0 = normalize(light);
-            out.coef = PI_F * brdf_cook_torrance(view, light, hit.normal, roughness, c.f0);
+        float a = roughness * roughness;
+        float angle = 2.0f * PI_F * (spec ? xi_x : xi_y);                                  // phi (:421) / theta (:435)
+        float sin_a, cos_a;
+        det::sincosf_(angle, sin_a, cos_a);
+        float under1 = spec ? (1.0f - xi_y) / (xi_y * (a * a - 1.0f) + 1.0f) : xi_x;       // cos_theta^2 (:423) / r^2 (:434)
+        float root1 = sqrt_ieee(under1);
+        float under2 = spec ? 1.0f - root1 * root1 : max_rs(0.0f, 1.0f - xi_x);            // sin_theta^2 (:424) / y^2 (:439)
+        float root2 = sqrt_ieee(under2);
+        float radial = spec ? root2 : root1;                                               // sin_theta / r
+        V3 local = v3(radial * cos_a, spec ? root1 : root2, radial * sin_a);               // :426-428 / :437-440
+        V3 world = to_basis(ts, local);
+        V3 light = spec ? reflect(direction, world) : world;                               // :553 / :563
+        out.d0 = normalize(light);
+        if (spec) {
+            out.coef = PI_F * brdf_cook_torrance(-direction, light, hit.normal, roughness, c.f0);
         } else {
-            V3 light = to_basis(ts, importance_sample_cos(xi_x, xi_y));
-            out.d0 = normalize(light);
             out.coef = PI_F * (color / PI_F);  // PI * brdf_lambert, :334-337,567
             out.coef_w = dot(light, hit.normal);
         }
