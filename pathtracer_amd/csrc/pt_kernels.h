@@ -360,8 +360,8 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
 // rows of the primitive IT hit (a divergent gather: two dependent round trips to the vector cache per record when
 // read from global memory; ~64-cycle LDS reads instead).  The intersection loop keeps its scalar loads: it reads
 // the same row in all lanes.
-constexpr int LDS_SCENE_CAP = 1024;  // float4 rows: n_sph + 4 n_pl + 2 (n_sph + n_pl) must fit (16 KiB)
-__host__ __device__ inline bool lds_scene_fits(uint32_t n_sph, uint32_t n_pl) { return 3ull * n_sph + 6ull * n_pl <= LDS_SCENE_CAP; }
+constexpr int LDS_SCENE_CAP = 1024;  // float4 rows: n_sph + 4 n_pl + 4 (n_sph + n_pl) must fit (16 KiB)
+__host__ __device__ inline bool lds_scene_fits(uint32_t n_sph, uint32_t n_pl) { return 5ull * n_sph + 8ull * n_pl <= LDS_SCENE_CAP; }
 
 // Wave-granular kernel: each wave takes 64 consecutive records.  FUSED: intersection here as well; RAYGEN: level 0
 // generates its primary rays in place; LDS_SCENE: see above (the host checks lds_scene_fits).
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
     DevScene lsc = sc;  // what the shading step reads
     if (LDS_SCENE) {
-        const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 2u * (sc.n_sph + sc.n_pl);
+        const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 4u * (sc.n_sph + sc.n_pl);
         for (uint32_t j = threadIdx.x; j < n_s; j += BLOCK) s_scene[j] = sc.sph[j];
         for (uint32_t j = threadIdx.x; j < n_p; j += BLOCK) s_scene[n_s + j] = sc.pln[j];
         for (uint32_t j = threadIdx.x; j < n_m; j += BLOCK) s_scene[n_s + n_p + j] = sc.mat[j];

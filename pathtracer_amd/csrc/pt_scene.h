@@ -33,7 +33,7 @@ struct DevScene {
     uint32_t n_pl_plain;     // non-emissive planes: emissive plane k has plane slot n_pl_plain + k
     const float4 *sph;       // [n_sph]      (origin.xyz, radius)
     const float4 *pln;       // [n_pl * 4]   (n.xyz, s.x) (s.yz, un.xy) (un.z, |u|, vn.xy) (vn.z, |v|, 0, 0)
-    const float4 *mat;       // [(n_sph + n_pl) * 2]  (kind, color.xyz) (roughness, metalness, ior, 0)
+    const float4 *mat;       // [(n_sph + n_pl) * 4]  (kind, color.xyz) (roughness, metalness, ior, 0) (f0.xyz, 0) (PI*lambert.xyz, 0)
     const float4 *lights;    // [n_es] radiance of emissive spheres, then [n_ep * 4] emissive planes:
                              //   (origin.xyz, n.x) (n.yz, u.xy) (u.z, v.xyz) (radiance.xyz, 0)
     const BvhNode *bvh_nodes;   // null: linear scan
@@ -275,6 +275,7 @@ PT_HD V3 sky_radiance(const DevScene &sc, V3 direction);
 struct ShadeCtx {
     Hit hit;
     float4 m0, m1;     // material rows
+    V3 pi_lambert;     // Physically: PI * brdf_lambert(reflectivity)
     V3 f0;             // Physically: mix(0.04, reflectivity, metalness)
     uint32_t kind;     // NK_* arm
     int n_children;
@@ -299,8 +300,8 @@ PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t p
     }
     const float SHIFT_AMOUNT = 0.0001f;  // :495
     const float R = 0.04f;               // :499
-    c.m0 = sc.mat[2 * prim];
-    c.m1 = sc.mat[2 * prim + 1];
+    c.m0 = sc.mat[4 * prim];
+    c.m1 = sc.mat[4 * prim + 1];
     uint32_t mat = f2u(c.m0.x);
     V3 color = v3(c.m0.y, c.m0.z, c.m0.w);
     V3 outwards = c.hit.position + SHIFT_AMOUNT * c.hit.normal;
@@ -316,13 +317,15 @@ PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t p
         c.o1 = outwards;
         return;
     default: {                                               // MAT_PHYSICALLY, :537-569
-        float metalness = c.m1.y;
-        c.f0 = (1.0f - metalness) * v3(R, R, R) + metalness * color;  // mix_vec3, src/common.rs:68-70
+        float4 m2 = sc.mat[4 * prim + 2];
+        c.f0 = v3(m2.x, m2.y, m2.z);  // mix_vec3(0.04, reflectivity, metalness), :543: a constant of the material
         float a = random32(rng_draw(node_key, 2));
         uint32_t ch = rng_draw(node_key, 3) % 3u;
         float f0c = ch == 0 ? c.f0.x : (ch == 1 ? c.f0.y : c.f0.z);
         c.kind = a < f0c ? NK_SPECULAR : NK_DIFFUSE;
         c.n_children = 1;
+        float4 m3 = sc.mat[4 * prim + 3];
+        c.pi_lambert = v3(m3.x, m3.y, m3.z);
         return;
     }
     }
@@ -381,7 +384,7 @@ PT_HD void shade_finish(const ShadeCtx &c, V3 direction, uint32_t node_key, Node
         if (spec) {
             out.coef = PI_F * brdf_cook_torrance(-direction, light, hit.normal, roughness, c.f0);
         } else {
-            out.coef = PI_F * (color / PI_F);  // PI * brdf_lambert, :334-337,567
+            out.coef = c.pi_lambert;  // PI * brdf_lambert(reflectivity), :334-337,567: a constant of the material
             out.coef_w = dot(light, hit.normal);
         }
         return;
@@ -399,14 +402,13 @@ PT_HD void shade_hit(const DevScene &sc, V3 origin, V3 direction, uint32_t prim,
 // The arm a hit will take, without rebuilding the hit (used to regroup rays by arm).
 PT_HD uint32_t shade_class(const DevScene &sc, uint32_t prim, uint32_t node_key) {
     if (prim == MISS) return NK_LEAF;
-    float4 m0 = sc.mat[2 * prim];
+    float4 m0 = sc.mat[4 * prim];
     uint32_t kind = f2u(m0.x);
     if (kind == MAT_NONE || kind == MAT_EMISSIVE) return NK_LEAF;
     if (kind == MAT_MIRROR) return NK_MIRROR;
     if (kind == MAT_TRANSLUCENT) return NK_GLASS;
-    const float R = 0.04f;
-    float metalness = sc.mat[2 * prim + 1].y;
-    V3 f0 = (1.0f - metalness) * v3(R, R, R) + metalness * v3(m0.y, m0.z, m0.w);
+    float4 m2 = sc.mat[4 * prim + 2];
+    V3 f0 = v3(m2.x, m2.y, m2.z);
     float a = random32(rng_draw(node_key, 2));
     uint32_t ch = rng_draw(node_key, 3) % 3u;
     float f0c = ch == 0 ? f0.x : (ch == 1 ? f0.y : f0.z);

@@ -132,6 +132,19 @@ inline V3 toV3(PtVec3 v) { return v3(v.x, v.y, v.z); }
 
 float4 mat0(const PtMaterial &m) { return make_float4(u2f((uint32_t)m.kind), m.color.x, m.color.y, m.color.z); }
 float4 mat1(const PtMaterial &m) { return make_float4(m.roughness, m.metalness, m.ior, 0.0f); }
+// Per-material constants of the Physically arm, computed once with the operations the reference performs per hit:
+// f0 = mix_vec3(&Vec3::new(R, R, R), &reflectivity, metalness) (src/tracer.rs:543, src/common.rs:68-70) and
+// PI * brdf_lambert(reflectivity) = PI * (reflectivity / PI) (src/tracer.rs:334-337,567).
+float4 mat2(const PtMaterial &m) {
+    const float R = 0.04f;
+    V3 color = toV3(m.color);
+    V3 f0 = (1.0f - m.metalness) * v3(R, R, R) + m.metalness * color;
+    return make_float4(f0.x, f0.y, f0.z, 0.0f);
+}
+float4 mat3(const PtMaterial &m) {
+    V3 pil = PI_F * (toV3(m.color) / PI_F);
+    return make_float4(pil.x, pil.y, pil.z, 0.0f);
+}
 
 // Per-plane constants of intersect_plane (reference src/scene.rs:244-249), computed once with the same operations.
 void pack_plane(const PtPlane &p, float4 *out) {
@@ -444,12 +457,12 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     free_scene(h);
 
     // ---- flatten (ids: spheres, emissive spheres, planes, emissive planes; reference src/scene.rs:266,280)
-    std::vector<float4> sph(n_sph), pln(4 * n_pl), mat(2 * (n_sph + n_pl)), lights(s->n_emissive_spheres + 4 * s->n_emissive_planes);
+    std::vector<float4> sph(n_sph), pln(4 * n_pl), mat(4 * (n_sph + n_pl)), lights(s->n_emissive_spheres + 4 * s->n_emissive_planes);
     bool glass = false;
     size_t id = 0;
     auto put_sphere = [&](const PtSphere &sp) {
         sph[id] = make_float4(sp.origin.x, sp.origin.y, sp.origin.z, sp.radius);
-        mat[2 * id] = mat0(sp.material); mat[2 * id + 1] = mat1(sp.material);
+        mat[4 * id] = mat0(sp.material); mat[4 * id + 1] = mat1(sp.material); mat[4 * id + 2] = mat2(sp.material); mat[4 * id + 3] = mat3(sp.material);
         glass |= sp.material.kind == PT_MAT_TRANSLUCENT;
         ++id;
     };
@@ -461,7 +474,7 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     }
     auto put_plane = [&](const PtPlane &p) {
         pack_plane(p, &pln[4 * (id - n_sph)]);
-        mat[2 * id] = mat0(p.material); mat[2 * id + 1] = mat1(p.material);
+        mat[4 * id] = mat0(p.material); mat[4 * id + 1] = mat1(p.material); mat[4 * id + 2] = mat2(p.material); mat[4 * id + 3] = mat3(p.material);
         glass |= p.material.kind == PT_MAT_TRANSLUCENT;
         ++id;
     };
