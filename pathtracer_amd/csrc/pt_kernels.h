@@ -387,9 +387,25 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
-        uint32_t i;
-        bool valid = tile_record(m, L, w, i);
+    // The rays of a wave's NEXT tile are requested before the current tile is traced and shaded, so their latency
+    // (an HBM round trip: the records were written by the previous launch) is covered by a whole tile of arithmetic.
+    uint32_t w = wave_global();
+    uint32_t i = 0;
+    bool valid = false;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    if (w < m.total) {
+        valid = tile_record(m, L, w, i);
+        if (!RAYGEN && valid) { ra = L.rayA[i]; rb = L.rayB[i]; }
+    }
+    while (w < m.total) {
+        const uint32_t w_next = w + waves_in_grid();
+        uint32_t i_next = 0;
+        bool valid_next = false;
+        float4 ra_next = make_float4(0.f, 0.f, 0.f, 0.f), rb_next = ra_next;
+        if (w_next < m.total) {
+            valid_next = tile_record(m, L, w_next, i_next);
+            if (!RAYGEN && valid_next) { ra_next = L.rayA[i_next]; rb_next = L.rayB[i_next]; }
+        }
         V3 o = v3(0.f, 0.f, 0.f), d = o;
         uint32_t skey = 0, node = 0, prim = MISS;
         float hit_t = 0.0f;
@@ -399,10 +415,9 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
                 primary_ray(sc, pp, i, o, d, skey);
                 node = 1u;
             } else {
-                float4 a = L.rayA[i], b = L.rayB[i];
-                o = v3(a.x, a.y, a.z); d = v3(a.w, b.x, b.y);
-                skey = f2u(b.z);
-                node = f2u(b.w);
+                o = v3(ra.x, ra.y, ra.z); d = v3(ra.w, rb.x, rb.y);
+                skey = f2u(rb.z);
+                node = f2u(rb.w);
             }
         }
         PT_STAMP(0);  // tile bookkeeping + ray fetch
@@ -417,6 +432,7 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
         shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr);
 #endif
         PT_STAMP(6);  // child stores
+        w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next;
     }
 #ifdef PT_STAMPS
     if (lane_id() == 0) for (int k = 0; k < 8; ++k) if (stamp_acc[k]) atomicAdd(&ctr->stamps[k], stamp_acc[k]);
