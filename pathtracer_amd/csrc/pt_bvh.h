@@ -66,23 +66,25 @@ __device__ __forceinline__ void box_entry2(f32x2 lox, f32x2 loy, f32x2 loz, f32x
 
 // A candidate replaces the current nearest when (t, id) is lexicographically smaller.
 // While nothing is hit, best == MISS (the largest id) and best_t == +inf, so the first hit always wins.
-__device__ __forceinline__ void bvh_accept(bool hit, float t, uint32_t id, uint32_t &best, float &best_t) {
-    if (hit && (t < best_t || (t == best_t && id < best))) { best = id; best_t = t; }
+__device__ __forceinline__ void bvh_accept(bool hit, float t, uint32_t id, int out, uint32_t &best, float &best_t, int &best_out) {
+    if (hit && (t < best_t || (t == best_t && id < best))) { best = id; best_t = t; best_out = out; }
 }
 
 // Primitives outside the tree (the `always` list), by id through the scene tables.
-__device__ __forceinline__ void bvh_test_prims(const DevScene &sc, const uint32_t *ids, uint32_t n, V3 o, V3 d, uint32_t &best, float &best_t) {
+__device__ __forceinline__ void bvh_test_prims(const DevScene &sc, const uint32_t *ids, uint32_t n, V3 o, V3 d, uint32_t &best, float &best_t,
+                                               int &best_out) {
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t id = ids[k];
         float t;
         bool hit;
-        if (id < sc.n_sph) hit = sphere_test(sc.sph[id], o, d, t);
+        int out = 0;
+        if (id < sc.n_sph) hit = sphere_test(sc.sph[id], o, d, t, out);
         else {
             uint32_t p = id - sc.n_sph;
             V3 pos;
             hit = plane_test(sc.pln[4 * p], sc.pln[4 * p + 1], sc.pln[4 * p + 2], sc.pln[4 * p + 3], o, d, t, pos);
         }
-        bvh_accept(hit, t, id, best, best_t);
+        bvh_accept(hit, t, id, out, best, best_t, best_out);
     }
 }
 
@@ -117,6 +119,7 @@ struct Trav {
     V3 o, d, inv, noi;   // noi = -o * inv
     uint32_t best;
     float best_t;
+    int best_out;        // Transition of the best hit (1: a sphere left from inside)
     int32_t node;
     int sp;
     uint32_t leaf_cur, leaf_end;
@@ -146,7 +149,8 @@ __device__ __forceinline__ void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &
     s.o = o; s.d = d;
     s.best = MISS;
     s.best_t = __builtin_inff();
-    bvh_test_prims(sc, sc.bvh_always, sc.n_always, o, d, s.best, s.best_t);
+    s.best_out = 0;
+    bvh_test_prims(sc, sc.bvh_always, sc.n_always, o, d, s.best, s.best_t, s.best_out);
     s.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     s.noi = v3(-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z));
     s.node = 0;
@@ -159,9 +163,10 @@ __device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, fl
     uint32_t id = __float_as_uint(e.w);
     float t;
     bool hit;
-    if (id < sc.n_sph) hit = sphere_test(a, s.o, s.d, t);
+    int out = 0;
+    if (id < sc.n_sph) hit = sphere_test(a, s.o, s.d, t, out);
     else { V3 pos; hit = plane_test(a, b, c, e, s.o, s.d, t, pos); }
-    bvh_accept(hit, t, id, s.best, s.best_t);
+    bvh_accept(hit, t, id, out, s.best, s.best_t, s.best_out);
 }
 
 // One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of up to 128 bytes, then either the four
@@ -211,12 +216,13 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
     return 2u;
 }
 
-__device__ __forceinline__ uint32_t bvh_nearest(const DevScene &sc, V3 o, V3 d, float &best_t) {
+__device__ __forceinline__ uint32_t bvh_nearest(const DevScene &sc, V3 o, V3 d, float &best_t, int &best_out) {
     Trav s;
     bvh_begin(sc, o, d, s);
     TravStack stk = trav_stack(sc);
     while (s.node != BVH_EMPTY) (void)bvh_step(sc, s, stk);
     best_t = s.best_t;
+    best_out = s.best_out;
     return s.best;
 }
 #endif  // __HIPCC__

@@ -40,7 +40,8 @@ struct Level {
     float4 *rayA;       // (origin.xyz, dir.x)
     float4 *rayB;       // (dir.y, dir.z, bits(sample id), bits(path node))
     uint32_t *parent;   // (parent record index << 1) | child slot
-    uint32_t *hitprim;  // primitive id of the nearest hit (unfused pipeline only)
+    uint32_t *hitprim;  // nearest hit: primitive id | HIT_OUT_BIT if Transition::Out, or MISS (two-kernel pipeline only)
+    float *hit_t;       // its distance (two-kernel pipeline only)
     uint32_t *meta;     // node kind
     float4 *coef;       // node coefficients (xyz, w)
     float4 *val0;       // radiance of child 0
@@ -143,9 +144,9 @@ __device__ __forceinline__ uint32_t sample_key_of(const DevScene &sc, const Pass
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef const f4_t __attribute__((address_space(4))) *const_f4_ptr;
 
-// `transition`: the winner's Transition when the search knows it (linear scan), -1 when it does not (BVH).
+// `transition`: the winner's Transition (0 In, 1 Out: a sphere left from inside).
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t, int &transition) {
-    if (sc.bvh_nodes) { transition = -1; return bvh_nearest(sc, o, d, t); }
+    if (sc.bvh_nodes) return bvh_nearest(sc, o, d, t, transition);
     return nearest_brute((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
 }
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t) {
@@ -172,6 +173,12 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, Level L0, PassPar
     }
 }
 
+// Primitive ids stay below 2^28, so bit 30 is free to carry the Transition of the hit next to the id.
+constexpr uint32_t HIT_OUT_BIT = 1u << 30;
+__device__ __forceinline__ uint32_t pack_hit(uint32_t prim, int transition) {
+    return prim == MISS ? MISS : (prim | (transition == 1 ? HIT_OUT_BIT : 0u));
+}
+
 // ---- trace: reference src/scene.rs:263-297 ------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
     TileMap m = tile_map(L);
@@ -180,7 +187,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
         if (!tile_record(m, L, w, i)) continue;
         float4 a = L.rayA[i], b = L.rayB[i];
         float t;
-        L.hitprim[i] = nearest_hit(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), t);
+        int tr;
+        uint32_t prim = nearest_hit(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), t, tr);
+        L.hitprim[i] = pack_hit(prim, tr);
+        L.hit_t[i] = t;
     }
 }
 
@@ -266,7 +276,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Count
 #endif
                 my_steps += bvh_step(sc, st, stk);
                 if (st.node == BVH_EMPTY) {
-                    L.hitprim[rec] = st.best;
+                    L.hitprim[rec] = pack_hit(st.best, st.best_out);
+                    L.hit_t[rec] = st.best_t;
                     active = false;
                 }
             }
@@ -423,7 +434,12 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
         PT_STAMP(0);  // tile bookkeeping + ray fetch
         if (valid) {
             if (FUSED) prim = nearest_hit(sc, o, d, hit_t, hit_tr);
-            else prim = L.hitprim[i];
+            else {  // the trace kernel left the winner, its Transition and its distance
+                uint32_t word = L.hitprim[i];
+                hit_t = L.hit_t[i];
+                prim = word == MISS ? MISS : (word & ~HIT_OUT_BIT);
+                hit_tr = (word != MISS && (word & HIT_OUT_BIT)) ? 1 : 0;
+            }
         }
         PT_STAMP(1);  // intersection
 #ifdef PT_STAMPS

@@ -221,7 +221,7 @@ int alloc_levels(PtHandle *h) {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
-    const uint64_t rec_bytes = 16 + 16 + 4 + 4 + 4 + 16 + 16 + 16;
+    const uint64_t rec_bytes = 16 + 16 + 4 + 4 + 4 + 4 + 16 + 16 + 16;
     const uint64_t budget = 48ull << 30;
     for (;;) {
         uint64_t total = 0;
@@ -271,6 +271,7 @@ int alloc_levels(PtHandle *h) {
             L.val1 = (float4 *)base; base += n * 16;
             L.parent = (uint32_t *)base; base += n * 4;
             L.hitprim = (uint32_t *)base; base += n * 4;
+            L.hit_t = (float *)base; base += n * 4;
             L.meta = (uint32_t *)base;
         }
     }
