@@ -105,7 +105,8 @@ typedef struct {
     uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records; 0 = 16 */
     int32_t accel;                /* PT_ACCEL_* */
     int32_t fuse_trace_shade;     /* 0: trace and shade kernels; 1: one fused kernel per level; 2: fused, and each block regroups
-                                     its rays by material arm before shading; -1: auto (BVH scenes 0, others 1) */
+                                     its rays by material arm before shading; 3: trace-ahead (a kernel shades its records and traces
+                                     their children; leaf children never become records); -1: auto (BVH scenes 0, others 1) */
     int32_t profile_events;       /* 1: bracket kernels with HIP events and report per-kernel time in PtStats */
     uint32_t concurrent_passes;   /* 1..4 pipeline passes in flight (own queues and HIP stream each; one fills the GPU while
                                      another drains its last long rays); 0 = auto (2 for BVH scenes, else 1) */
@@ -123,6 +124,7 @@ typedef struct {
     uint64_t rays;                            /* nearest-hit queries (primary + bounce + shadow) since clear */
     uint64_t shadow_rays;                     /* the part of `rays` traced by terminal light samples */
     uint64_t records;                         /* queue records processed over all levels since clear */
+    uint64_t terminal_records;                /* the part of `records` on the last level (terminal light samples that need a shadow ray) */
     uint64_t bvh_nodes, bvh_leaf_prims;       /* size of the current BVH (0 for brute force) */
     uint64_t bvh_steps;                       /* 64-byte fetches (inner nodes + leaf primitives) made by the BVH trace kernel since clear */
     uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */

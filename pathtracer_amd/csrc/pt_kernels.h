@@ -57,7 +57,7 @@ struct PassParams {
 };
 
 // device-side counters (one allocation)
-struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow, bvh_steps; unsigned long long stamps[8]; };
+struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow, bvh_steps, terminal; unsigned long long stamps[8]; };
 
 // Diagnostic builds (-DPT_STAMPS) time the phases of the fused kernel with s_memtime; never part of a shipped build.
 #ifdef PT_STAMPS
@@ -455,6 +455,160 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
 #endif
 }
 
+// ---- trace-ahead pipeline (small scenes) ---------------------------------------------------------------------------
+// The same recursion with the nearest-hit query moved from the head of a level to the tail of its parent: a
+// kernel shades its records (whose hit is already known), generates the child rays AND traces them at once.  A
+// child that ends on the sky or on an emitter is a leaf: its radiance goes straight into this node's own val slot
+// and it never becomes a record.  Measured on the sample scene about 40 % of the rays below the primary ones are
+// such leaves; they used to cost a 36-byte record write, a 32-byte read, a scattered 16-byte write into the
+// parent and, worst, an idle lane through the whole shading step of their wave.  Records of levels >= 1 carry
+// (primitive | transition bit, distance) next to the ray, so every lane of a deeper-level wave has real work.
+// The linear scan alone (the host selects this pipeline only for scenes without a BVH).
+__device__ __forceinline__ uint32_t scan_nearest(const DevScene &sc, V3 o, V3 d, float &t, int &transition) {
+    return nearest_brute((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
+}
+
+__device__ __forceinline__ bool child_is_leaf(const DevScene &sc, const DevScene &lsc, uint32_t prim, V3 dir, V3 &value) {
+    if (prim == MISS) { value = sky_radiance(sc, dir); return true; }                    // reference src/tracer.rs:571-583
+    float4 m0 = lsc.mat[4 * prim];
+    uint32_t mat = f2u(m0.x);
+    if (mat == MAT_NONE) { value = v3(1.0f, 1.0f, 1.0f); return true; }                  // :502
+    if (mat == MAT_EMISSIVE) { value = v3(m0.y, m0.z, m0.w); return true; }              // :503-505
+    return false;
+}
+
+#ifndef PT_AHEAD_WAVES
+#define PT_AHEAD_WAVES 3
+#endif
+template <bool RAYGEN, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Level L, Level Lnext, PassParams pp, uint32_t level,
+                                                               uint32_t last_traced, uint32_t *traced_count, Counters *ctr) {
+    __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
+    DevScene lsc = sc;  // what the shading step reads
+    if (LDS_SCENE) {
+        const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 4u * (sc.n_sph + sc.n_pl);
+        for (uint32_t j = threadIdx.x; j < n_s; j += BLOCK) s_scene[j] = sc.sph[j];
+        for (uint32_t j = threadIdx.x; j < n_p; j += BLOCK) s_scene[n_s + j] = sc.pln[j];
+        for (uint32_t j = threadIdx.x; j < n_m; j += BLOCK) s_scene[n_s + n_p + j] = sc.mat[j];
+        __syncthreads();
+        lsc.sph = s_scene;
+        lsc.pln = s_scene + n_s;
+        lsc.mat = s_scene + n_s + n_p;
+    }
+    TileMap m = tile_map(L);
+    const uint32_t shard = my_shard();
+    uint32_t n_traced = 0;  // nearest-hit queries of this wave (wave-uniform)
+    // the next tile's records are requested before the current tile is processed
+    uint32_t w = wave_global();
+    uint32_t i = 0;
+    bool valid = false;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    uint32_t rp = MISS;
+    float rt = 0.0f;
+    if (w < m.total) {
+        valid = tile_record(m, L, w, i);
+        if (!RAYGEN && valid) { ra = L.rayA[i]; rb = L.rayB[i]; rp = L.hitprim[i]; rt = L.hit_t[i]; }
+    }
+    while (w < m.total) {
+        const uint32_t w_next = w + waves_in_grid();
+        uint32_t i_next = 0;
+        bool valid_next = false;
+        float4 ra_next = make_float4(0.f, 0.f, 0.f, 0.f), rb_next = ra_next;
+        uint32_t rp_next = MISS;
+        float rt_next = 0.0f;
+        if (w_next < m.total) {
+            valid_next = tile_record(m, L, w_next, i_next);
+            if (!RAYGEN && valid_next) { ra_next = L.rayA[i_next]; rb_next = L.rayB[i_next]; rp_next = L.hitprim[i_next]; rt_next = L.hit_t[i_next]; }
+        }
+        V3 o = v3(0.f, 0.f, 0.f), d = o;
+        uint32_t skey = 0, node = 0, prim = MISS;
+        float hit_t = 0.0f;
+        int hit_tr = 0;
+        if (valid) {
+            if (RAYGEN) {
+                primary_ray(sc, pp, i, o, d, skey);
+                node = 1u;
+                prim = scan_nearest(sc, o, d, hit_t, hit_tr);
+            } else {
+                o = v3(ra.x, ra.y, ra.z); d = v3(ra.w, rb.x, rb.y);
+                skey = f2u(rb.z);
+                node = f2u(rb.w);
+                prim = rp & ~HIT_OUT_BIT;  // never MISS: leaves are not queued
+                hit_tr = (rp & HIT_OUT_BIT) ? 1 : 0;
+                hit_t = rt;
+            }
+        }
+        if (RAYGEN) n_traced += (uint32_t)__popcll(__ballot(valid));
+        // ---- this node: reference src/tracer.rs:494-569
+        const uint32_t nkey = rng_node_key(skey, node);
+        ShadeCtx c;
+        c.n_children = 0;
+        NodeOut out;
+        if (valid) {
+            shade_prepare(lsc, o, d, prim, hit_t, hit_tr, nkey, c);
+            shade_finish(c, d, nkey, out);
+            // (only a primary ray can be a leaf here; the resolve step reads its radiance from coef)
+            L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.kind == NK_LEAF ? 0.0f : out.coef_w);
+            L.meta[i] = out.kind;
+        }
+        bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
+        uint32_t hp0 = MISS, hp1 = MISS;
+        float t0 = 0.0f, t1 = 0.0f;
+        if (last_traced) {
+            // children have depth 0: terminal light samples (:451-492); the ones that need no shadow ray are black
+            V3 dir, rad;
+            float dist;
+            if (has0 && !terminal_sample(sc, c.o0, rng_node_key(skey, 2u * node), dir, dist, rad)) {
+                L.val0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                has0 = false;
+            }
+            if (has1 && !terminal_sample(sc, c.o1, rng_node_key(skey, 2u * node + 1u), dir, dist, rad)) {
+                L.val1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                has1 = false;
+            }
+        } else {
+            // ---- the children's nearest hits, now (:448-449 of the callee); one copy of the scan serves both slots
+            n_traced += (uint32_t)__popcll(__ballot(has0)) + (uint32_t)__popcll(__ballot(has1));
+#pragma unroll 1
+            for (int slot = 0; slot < 2; ++slot) {
+                const bool has = slot == 0 ? has0 : has1;
+                if (__ballot(has) == 0) continue;  // (slot 1 exists only under glass)
+                if (has) {
+                    V3 co = slot == 0 ? out.o0 : out.o1, cd = slot == 0 ? out.d0 : out.d1;
+                    float ct;
+                    int tr;
+                    uint32_t p = scan_nearest(sc, co, cd, ct, tr);
+                    V3 value;
+                    const bool leaf = child_is_leaf(sc, lsc, p, cd, value);
+                    if (leaf) {
+                        float4 v = make_float4(value.x, value.y, value.z, 0.0f);
+                        if (slot == 0) L.val0[i] = v; else L.val1[i] = v;
+                    }
+                    if (slot == 0) { has0 = !leaf; hp0 = pack_hit(p, tr); t0 = ct; }
+                    else { has1 = !leaf; hp1 = pack_hit(p, tr); t1 = ct; }
+                }
+            }
+        }
+        Reservation rsv = wave_reserve(Lnext, shard, has0, has1);
+        uint32_t i0, i1;
+        wave_resolve(Lnext, shard, rsv, has0, has1, i0, i1, ctr);
+        if (has0) {
+            Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
+            Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
+            Lnext.parent[i0] = (i << 1);
+            if (!last_traced) { Lnext.hitprim[i0] = hp0; Lnext.hit_t[i0] = t0; }
+        }
+        if (has1) {
+            Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
+            Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
+            Lnext.parent[i1] = (i << 1) | 1u;
+            if (!last_traced) { Lnext.hitprim[i1] = hp1; Lnext.hit_t[i1] = t1; }
+        }
+        w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next; rp = rp_next; rt = rt_next;
+    }
+    if (n_traced != 0 && lane_id() == 0) atomicAdd(&traced_count[shard * CSTRIDE], n_traced);
+}
+
 // Block-granular kernel: the 256 records a block takes per step are intersected first, then REGROUPED through LDS
 // by the match arm they will take (shade_class), so that three of the block's four waves typically run one arm of
 // the material switch instead of all of them (the arms differ by hundreds of instructions: GGX + Cook-Torrance vs
@@ -626,27 +780,32 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassPa
 // ---- bookkeeping -----------------------------------------------------------------------------------------------
 // Adds this pass's record/ray counts to the running totals: rays = records of the traced levels 0..D-1;
 // row n_levels of `counts` holds the shadow rays counted by k_terminal.
-__global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, Counters *ctr) {
+// Row n_levels + 1 holds the nearest-hit queries counted by the trace-ahead kernels (`ahead`: there a ray is no
+// longer the same thing as a record); `terminal` = records of the last level (terminal light samples queued).
+__global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, int ahead, Counters *ctr) {
     // one wave: lane q sums shard q over the levels, then a shuffle reduction
     const int q = threadIdx.x & 63;
-    unsigned long long rec = 0, rays = 0;
+    unsigned long long rec = 0, rays = 0, terminal = 0;
     for (int l = 0; l < n_levels; ++l) {
         uint32_t c = counts[(l * NSHARD + q) * CSTRIDE];
         uint32_t cap = shard_caps[l];
         unsigned long long n = c < cap ? c : cap;
         rec += n;
-        if (l < n_levels - 1) rays += n;
+        if (l < n_levels - 1) rays += n; else terminal = n;
     }
+    if (ahead) rays = counts[((n_levels + 1) * NSHARD + q) * CSTRIDE];
     unsigned long long shadow = counts[(n_levels * NSHARD + q) * CSTRIDE];
     for (int o = 32; o > 0; o >>= 1) {
         rec += __shfl_down(rec, o);
         rays += __shfl_down(rays, o);
         shadow += __shfl_down(shadow, o);
+        terminal += __shfl_down(terminal, o);
     }
     if (q == 0) {
         ctr->records += rec;
         ctr->rays += rays;
         ctr->shadow += shadow;
+        ctr->terminal += terminal;
     }
 }
 

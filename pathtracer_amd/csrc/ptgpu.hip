@@ -70,6 +70,7 @@ struct PtHandle {
     uint32_t *d_shard_caps = nullptr;  // [n_levels]
     Counters *d_ctr = nullptr;
     bool fused = true;
+    bool ahead = false;           // trace-ahead pipeline: a kernel shades its records and traces their children (fuse_trace_shade 3)
     bool lds_scene = false;       // primitive/material tables fit the shade kernel's LDS copy
     bool regroup = true;          // fused kernel regroups each block's records by material arm (fuse_trace_shade 2 / auto)
     size_t lds_bytes = 0;
@@ -240,8 +241,8 @@ int alloc_levels(PtHandle *h) {
     for (int q = 0; q < h->n_pipes; ++q) {
         Pipe &pipe = h->pipes[q];
         pipe.levels.resize(h->n_levels);
-        if ((rc = dev_alloc(h, &pipe.d_counts, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE))) return rc;
-        HIPCHK(h, hipMemsetAsync(pipe.d_counts, 0, (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE * 4, h->stream));
+        if ((rc = dev_alloc(h, &pipe.d_counts, (size_t)(h->n_levels + 2) * NSHARD * CSTRIDE))) return rc;
+        HIPCHK(h, hipMemsetAsync(pipe.d_counts, 0, (size_t)(h->n_levels + 2) * NSHARD * CSTRIDE * 4, h->stream));
         pipe.sc = h->sc;
         if (h->sc.bvh_nodes) {
             if ((rc = dev_alloc(h, &pipe.d_bvh_spill, (size_t)(BVH_STACK - BVH_LDS_ENTRIES) * BVH_TRAV_BLOCKS * BVH_STACK_STRIDE))) return rc;
@@ -306,9 +307,9 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     // kernels that walk the BVH index a per-thread spill area sized for BVH_TRAV_BLOCKS blocks
     const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
-    HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 1) * NSHARD * CSTRIDE * 4, st));  // levels 1..D + shadow row
+    HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
     k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap);
-    if (!h->fused) {
+    if (!h->fused && !h->ahead) {
         Span s(h, PT_KERNEL_RAYGEN, st);
         k_raygen<<<flat_grid, BLOCK, 0, st>>>(sc, levels[0], pp, S);
     }
@@ -317,7 +318,17 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         Level &Lp = levels[l > 0 ? l - 1 : 0];
         Level &Ln = levels[l + 1];
         const uint32_t last = (l == D - 1) ? 1u : 0u;
-        if (h->fused) {
+        if (h->ahead) {
+            Span s(h, PT_KERNEL_TRACE_SHADE, st);
+            uint32_t *traced_row = pipe.d_counts + (size_t)(h->n_levels + 1) * NSHARD * CSTRIDE;
+            if (h->lds_scene) {
+                if (l == 0) k_ahead<true, true><<<TG, BLOCK, lds, st>>>(sc, L, Ln, pp, 0u, last, traced_row, h->d_ctr);
+                else k_ahead<false, true><<<TG, BLOCK, lds, st>>>(sc, L, Ln, pp, (uint32_t)l, last, traced_row, h->d_ctr);
+            } else {
+                if (l == 0) k_ahead<true, false><<<TG, BLOCK, lds, st>>>(sc, L, Ln, pp, 0u, last, traced_row, h->d_ctr);
+                else k_ahead<false, false><<<TG, BLOCK, lds, st>>>(sc, L, Ln, pp, (uint32_t)l, last, traced_row, h->d_ctr);
+            }
+        } else if (h->fused) {
             Span s(h, PT_KERNEL_TRACE_SHADE, st);
             if (h->regroup) {
                 if (l == 0) k_shade_sorted<true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
@@ -357,7 +368,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         Span s(h, PT_KERNEL_RESOLVE, st);
         k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], pp, spp, h->d_pixels32);
     }
-    k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->d_ctr);
+    k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->ahead ? 1 : 0, h->d_ctr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(pipe.resolved, st));
     pipe.resolved_pending = true;
@@ -570,7 +581,8 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     // auto: BVH scenes run intersection as its own kernel (dynamic ray fetch), small scenes fuse it with shading
     h->fused = h->cfg.fuse_trace_shade < 0 ? (sc.bvh_nodes == nullptr) : (h->cfg.fuse_trace_shade != 0);
     h->lds_scene = lds_scene_fits(sc.n_sph, sc.n_pl);
-    h->regroup = h->cfg.fuse_trace_shade >= 2;  // measured no faster than the plain fused kernel: opt-in only
+    h->regroup = h->cfg.fuse_trace_shade == 2;  // measured no faster than the plain fused kernel: opt-in only
+    h->ahead = h->cfg.fuse_trace_shade == 3 && sc.bvh_nodes == nullptr;
 
     // ---- accumulators and queues
     const size_t P = (size_t)s->width * s->height;
@@ -730,6 +742,7 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         for (int k = 0; k < 8; ++k) out->debug_cycles[k] = c.stamps[k];
         out->records = c.records;
         out->bvh_steps = c.bvh_steps;
+        out->terminal_records = c.terminal;
         out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
     }
     out->bvh_nodes = h->bvh_nodes;

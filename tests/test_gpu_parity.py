@@ -281,3 +281,20 @@ def test_thin_lens_camera_bit_exact(binding, oracle):
         gpu.upload_scene(sc)
         gpu.render(5)
         assert not np.array_equal(gpu.read_pixels32()[0], r32)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_every_pipeline_variant_is_bit_exact(binding, oracle, mode, depth):
+    """fuse_trace_shade 0 (trace + shade kernels), 1 (fused), 2 (fused, block regroup by material arm) and
+    3 (trace-ahead: children traced by the parent's kernel, leaf children never queued) all evaluate the same
+    recursion: same sums, same ray counts as the oracle, on the scene with every material, both light kinds and
+    an open sky (so that leaves are common)."""
+    sc = materials_scene(112, 80)
+    p32, p8, _, st = _gpu_render(binding, sc, 4, fuse_trace_shade=mode, max_depth=depth)
+    osc = oracle.OracleScene(sc)
+    r32, r8, rays = osc.render(oracle.options(max_depth=depth), 4)
+    assert np.array_equal(p32, r32) and np.array_equal(p8, r8)
+    assert st["rays"] == rays
+    if mode == 3 and depth > 1:
+        assert st["records"] < rays  # leaf children were not queued
