@@ -212,11 +212,12 @@ int alloc_levels(PtHandle *h) {
     const int D = h->cfg.max_depth;
     h->n_levels = D + 1;
     uint32_t branch_cap = h->cfg.branch_capacity ? h->cfg.branch_capacity : 16u;
-    // samples per pixel per pass: about 8M records at level 0 (fewer, larger launches: +5 % over 4M), bounded by a
+    // samples per pixel per pass: about 16M records at level 0 (fewer, larger launches), bounded by a
     // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
     uint32_t b = h->cfg.samples_per_batch;
-    // (BVH scenes: 16M - a launch ends with a few rays that walk hundreds of nodes, and longer launches dilute that)
-    const uint64_t target = h->sc.bvh_nodes ? (16u << 20) : (8u << 20);
+    // (16M records at level 0: measured +2 % over 8M on the sample scene, +15 % on BVH scenes, where a launch ends
+    // with a few rays that walk hundreds of nodes and longer launches dilute that)
+    const uint64_t target = 16u << 20;
     if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
