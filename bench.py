@@ -59,7 +59,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=0, help="0 = 8 (one pipeline pass at 1080p; quads: 16, two passes)")
+    ap.add_argument("--spp-per-step", type=int, default=0, help="0 = 32: several pipeline passes per step, so that a step is ~10-30 ms and the one all-reduce of a multi-GPU run is small beside it")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=0, help="0 = the workload's own (4; 16 for room)")
@@ -103,7 +103,7 @@ def main() -> None:
         wl = f"closed diffuse room, 27 primitives (seed 777) at {args.width}x{args.height}"
         depth = args.max_depth or 16
     args.max_depth = depth
-    args.spp_per_step = args.spp_per_step or (16 if args.workload == "quads" else 8)
+    args.spp_per_step = args.spp_per_step or 32
     gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, max_depth=args.max_depth,
                         fuse_trace_shade=args.fused, samples_per_batch=args.batch, profile_events=0 if args.no_events else 1)
     gpu.upload_scene(sc)
