@@ -42,7 +42,11 @@ constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 
 #endif
 constexpr int BVH_LDS_ENTRIES = PT_BVH_LDS_ENTRIES;    // of which this many live in LDS, the rest (rarely reached) in a global spill area
 constexpr int BVH_STACK_STRIDE = 256;  // threads per block of every kernel that traverses
-constexpr int BVH_MAX_LEAF = 4;
+#ifndef PT_BVH_MAX_LEAF
+#define PT_BVH_MAX_LEAF 1
+#endif
+constexpr int BVH_MAX_LEAF = PT_BVH_MAX_LEAF;  // primitives per leaf (at most 8: three bits of the leaf reference); measured on the
+                                               // 1M-rectangle field: 1 -> 3750, 2 -> 3650, 3 -> 3560, 4 -> 3440, 8 -> 3140 Mrays/s
 constexpr uint32_t BVH_TRAV_BLOCKS = 2048;  // most blocks a traversing kernel is launched with (sizes the spill area)
 
 #if defined(__HIPCC__)
