@@ -102,7 +102,9 @@ typedef struct {
     uint32_t shard_index;         /* this handle renders global sample indices s with s % shard_count == shard_index */
     uint32_t shard_count;
     uint32_t samples_per_batch;   /* samples per pixel traced per pipeline pass; 0 = auto */
-    uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records; 0 = 16 */
+    uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records and an overflow is
+                                     PT_ERR_QUEUE_OVERFLOW; 0 = start at 2 and grow: a pass that overflows adds nothing and is
+                                     rendered again, with the levels re-allocated twice as large, at the next synchronisation */
     int32_t accel;                /* PT_ACCEL_* */
     int32_t fuse_trace_shade;     /* 0: trace and shade kernels; 1: one fused kernel per level; 2: fused, and each block regroups
                                      its rays by material arm before shading; 3: trace-ahead (a kernel shades its records and traces
@@ -130,6 +132,7 @@ typedef struct {
     uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */
     double kernel_ms[PT_KERNEL_COUNT];        /* since clear (profile_events only) */
     uint64_t device_bytes;                    /* device memory held by the handle */
+    uint64_t queue_growth;                    /* queue level l holds min(2^l, queue_growth) records per sample (1 without glass) */
     uint64_t debug_cycles[8];                 /* per-phase shader cycles of the fused kernel; diagnostic builds only, else 0 */
 } PtStats;
 

@@ -58,7 +58,7 @@ class PtConfig(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("records", C.c_uint64), ("terminal_records", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_leaf_prims", C.c_uint64), ("bvh_steps", C.c_uint64), ("kernel_launches", C.c_uint64 * PT_KERNEL_COUNT),
-                ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64), ("debug_cycles", C.c_uint64 * 8)]
+                ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64), ("queue_growth", C.c_uint64), ("debug_cycles", C.c_uint64 * 8)]
 
 
 class PtGpuError(RuntimeError):
@@ -257,7 +257,7 @@ class PtGpu:
         self._chk(self.lib.ptgpu_get_stats(self.h, C.byref(st)))
         return {
             "samples": st.samples, "rays": st.rays, "shadow_rays": st.shadow_rays, "records": st.records, "terminal_records": st.terminal_records, "bvh_nodes": st.bvh_nodes,
-            "bvh_leaf_prims": st.bvh_leaf_prims, "bvh_steps": st.bvh_steps, "device_bytes": st.device_bytes,
+            "bvh_leaf_prims": st.bvh_leaf_prims, "bvh_steps": st.bvh_steps, "device_bytes": st.device_bytes, "queue_growth": st.queue_growth,
             "kernel_launches": {KERNEL_NAMES[k]: st.kernel_launches[k] for k in range(PT_KERNEL_COUNT)},
             "kernel_ms": {KERNEL_NAMES[k]: st.kernel_ms[k] for k in range(PT_KERNEL_COUNT)},
             "debug_cycles": [int(st.debug_cycles[k]) for k in range(8)],

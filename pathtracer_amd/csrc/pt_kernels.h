@@ -47,6 +47,7 @@ struct Level {
     float4 *val0;       // radiance of child 0
     float4 *val1;       // radiance of child 1 (glass reflection)
     uint32_t *count;    // [NSHARD * CSTRIDE] records per shard, shard q at count[q * CSTRIDE]
+    uint32_t *overflow; // this pass's flag: set when an append found a level full (the pass is then not accumulated)
     uint32_t shard_cap;
 };
 
@@ -118,8 +119,8 @@ __device__ __forceinline__ void wave_resolve(const Level &L, uint32_t shard, con
     i0 = i1 = 0;
     if (total == 0) return;
     uint32_t base = __shfl(r.base, 0);
-    if (base + total > L.shard_cap) {  // never drop silently: the host turns this into PT_ERR_QUEUE_OVERFLOW
-        if (lane_id() == 0) atomicOr(&ctr->overflow, 1u);
+    if (base + total > L.shard_cap) {  // never drop silently: the pass is voided and the host re-runs it with larger levels
+        if (lane_id() == 0) atomicOr(L.overflow, 1u);
         has0 = has1 = false;
         return;
     }
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
 // One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + pixel) into
 // its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassParams pp, uint32_t spp, uint32_t *pixels32) {
+    if (*L0.overflow != 0u) return;  // a level overflowed somewhere in this pass: it adds nothing (the host repeats it)
     // the quantiser's threshold table is searched 24 times per sample with per-lane indices: keep it in LDS
     __shared__ float s_gamma[256];
     if (sc.gamma_table != nullptr) {
@@ -791,7 +793,8 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassPa
 // row n_levels of `counts` holds the shadow rays counted by k_terminal.
 // Row n_levels + 1 holds the nearest-hit queries counted by the trace-ahead kernels (`ahead`: there a ray is no
 // longer the same thing as a record); `terminal` = records of the last level (terminal light samples queued).
-__global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, int ahead, Counters *ctr) {
+__global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, int n_levels, int ahead, const uint32_t *overflow, Counters *ctr) {
+    if (*overflow != 0u) return;  // a voided pass is not counted either
     // one wave: lane q sums shard q over the levels, then a shuffle reduction
     const int q = threadIdx.x & 63;
     unsigned long long rec = 0, rays = 0, terminal = 0;

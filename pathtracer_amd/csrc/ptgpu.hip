@@ -26,6 +26,7 @@ struct EventSpan { int kernel; hipEvent_t start, stop; };
 // What one pipeline pass owns: its queues, counters, stream and (BVH scenes) traversal spill area.  Passes on
 // different pipes overlap on the GPU; only the accumulation into the pixel sums is ordered between them.
 constexpr int PT_MAX_PIPES = 4;
+constexpr uint32_t FLAG_RING = 1024;
 struct Pipe {
     hipStream_t stream = nullptr;      // pipe 0 uses the handle's stream
     hipEvent_t resolved = nullptr;     // recorded after the pass has added its samples to the accumulator
@@ -69,12 +70,22 @@ struct PtHandle {
     Pipe pipes[PT_MAX_PIPES];
     uint32_t *d_shard_caps = nullptr;  // [n_levels]
     Counters *d_ctr = nullptr;
+    // Levels of a scene with glass are sized for `growth`-fold branching, not for the worst case 2^depth.  Every pass
+    // has an overflow flag; a pass that filled a level adds nothing to the accumulator and is repeated, after the
+    // levels have been re-allocated with twice the growth, when the host next synchronises.
+    uint32_t growth = 2;
+    bool fixed_capacity = false;       // PtConfig.branch_capacity given: no re-allocation, overflow is an error
+    uint32_t *d_flags = nullptr;       // [FLAG_RING] one flag per pass in flight
+    uint64_t flag_cursor = 0;
+    struct Pending { uint32_t slot, spp, first; };
+    std::vector<Pending> pending;
     bool fused = true;
     bool ahead = false;           // trace-ahead pipeline: a kernel shades its records and traces their children (fuse_trace_shade 3)
     bool lds_scene = false;       // primitive/material tables fit the shade kernel's LDS copy
     bool regroup = true;          // fused kernel regroups each block's records by material arm (fuse_trace_shade 2 / auto)
     size_t lds_bytes = 0;
     uint64_t device_bytes = 0;
+    uint64_t level_bytes = 0;      // the part of device_bytes held by queue levels
 
     // profiling
     std::vector<EventSpan> spans;
@@ -113,18 +124,30 @@ void dev_free(T *&p) {
     p = nullptr;
 }
 
-void free_scene(PtHandle *h) {
-    dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
-    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always);
-    dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
+void free_levels(PtHandle *h) {
     for (Pipe &p : h->pipes) {
         for (void *a : p.level_allocs) (void)hipFree(a);
         p.level_allocs.clear();
         p.levels.clear();
-        dev_free(p.d_counts); dev_free(p.d_bvh_spill);
+        if (p.d_counts) { h->device_bytes -= (uint64_t)(h->n_levels + 2) * NSHARD * CSTRIDE * 4; }
+        dev_free(p.d_counts);
+        if (p.d_bvh_spill) { h->device_bytes -= (uint64_t)(BVH_STACK - BVH_LDS_ENTRIES) * BVH_TRAV_BLOCKS * BVH_STACK_STRIDE * sizeof(uint2); }
+        dev_free(p.d_bvh_spill);
         p.resolved_pending = false;
     }
-    dev_free(h->d_shard_caps); dev_free(h->d_ctr);
+    h->device_bytes -= h->level_bytes;
+    h->level_bytes = 0;
+    if (h->d_shard_caps) h->device_bytes -= (uint64_t)h->n_levels * 4;
+    dev_free(h->d_shard_caps);
+}
+
+void free_scene(PtHandle *h) {
+    dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
+    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always);
+    dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
+    free_levels(h);
+    dev_free(h->d_ctr); dev_free(h->d_flags);
+    h->pending.clear();
     h->have_scene = false;
     h->device_bytes = 0;
 }
@@ -189,7 +212,8 @@ int drain_spans(PtHandle *h) {
     return PT_OK;
 }
 
-__global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t shard_cap) {
+__global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t shard_cap, uint32_t *overflow) {
+    if (threadIdx.x == 0) *overflow = 0u;
     uint32_t q = threadIdx.x;
     uint64_t start = (uint64_t)q * shard_cap;
     uint32_t c = 0;
@@ -211,7 +235,7 @@ int alloc_levels(PtHandle *h) {
     const uint32_t P = h->sc.width * h->sc.height;
     const int D = h->cfg.max_depth;
     h->n_levels = D + 1;
-    uint32_t branch_cap = h->cfg.branch_capacity ? h->cfg.branch_capacity : 16u;
+    const uint32_t branch_cap = h->growth;
     // samples per pixel per pass: about 16M records at level 0 (fewer, larger launches), bounded by a
     // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
     uint32_t b = h->cfg.samples_per_batch;
@@ -236,7 +260,6 @@ int alloc_levels(PtHandle *h) {
     std::vector<uint32_t> caps(h->n_levels);
     int rc;
     if ((rc = dev_alloc(h, &h->d_shard_caps, (size_t)h->n_levels))) return rc;
-    if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
     h->n_pipes = pipes_wanted(h);
     h->passes = 0;
     for (int q = 0; q < h->n_pipes; ++q) {
@@ -265,6 +288,7 @@ int alloc_levels(PtHandle *h) {
             char *base = nullptr;
             HIPCHK(h, hipMalloc((void **)&base, bytes));
             h->device_bytes += bytes;
+            h->level_bytes += bytes;
             pipe.level_allocs.push_back(base);
             L.rayA = (float4 *)base; base += n * 16;
             L.rayB = (float4 *)base; base += n * 16;
@@ -278,7 +302,6 @@ int alloc_levels(PtHandle *h) {
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_shard_caps, caps.data(), caps.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PT_OK;
 }
@@ -309,7 +332,12 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
     HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
-    k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap);
+    // this pass's overflow flag: a slot of the ring, remembered until the host has looked at it
+    const uint32_t slot = (uint32_t)(h->flag_cursor++ % FLAG_RING);
+    uint32_t *flag = h->d_flags + slot;
+    for (Level &L : levels) L.overflow = flag;
+    h->pending.push_back({slot, spp, local_first});
+    k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap, flag);
     if (!h->fused && !h->ahead) {
         Span s(h, PT_KERNEL_RAYGEN, st);
         k_raygen<<<flat_grid, BLOCK, 0, st>>>(sc, levels[0], pp, S);
@@ -369,7 +397,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         Span s(h, PT_KERNEL_RESOLVE, st);
         k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], pp, spp, h->d_pixels32);
     }
-    k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->ahead ? 1 : 0, h->d_ctr);
+    k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(pipe.resolved, st));
     pipe.resolved_pending = true;
@@ -384,14 +412,49 @@ int sync_pipes(PtHandle *h) {
     return PT_OK;
 }
 
-int check_overflow(PtHandle *h) {
-    Counters c;
-    HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (c.overflow)
-        return fail(h, PT_ERR_QUEUE_OVERFLOW,
-                    "a ray queue level overflowed (glass branching beyond branch_capacity); accumulators are incomplete");
-    return PT_OK;
+// Looks at the overflow flags of the passes launched since the last look (all streams idle).  Voided passes are
+// repeated: with the levels re-allocated for twice the branching each time round, which ends at the latest when a
+// level can hold 2^level records per sample.  With a fixed PtConfig.branch_capacity an overflow is an error instead.
+int resolve_pending(PtHandle *h) {
+    struct Range { uint32_t first, spp; };
+    std::vector<Range> todo;  // sample ranges (per pixel) still to be rendered again, served from the back
+    for (;;) {
+        // ---- look at the flags of everything launched since the last look
+        if (!h->pending.empty()) {
+            std::vector<uint32_t> flags(FLAG_RING);
+            HIPCHK(h, hipMemcpy(flags.data(), h->d_flags, FLAG_RING * 4, hipMemcpyDeviceToHost));
+            bool any = false;
+            for (const auto &p : h->pending)
+                if (flags[p.slot]) { todo.push_back({p.first, p.spp}); any = true; }
+            h->pending.clear();
+            if (any) {
+                if (h->fixed_capacity)
+                    return fail(h, PT_ERR_QUEUE_OVERFLOW,
+                                "a ray queue level overflowed (glass branching beyond branch_capacity); the samples of that pass are missing");
+                if (h->growth >= (1u << 30)) return fail(h, PT_ERR_QUEUE_OVERFLOW, "a ray queue level overflowed at full capacity");
+                h->growth *= 2;
+                free_levels(h);
+                int rc = alloc_levels(h);
+                if (rc) return rc;
+            }
+        }
+        if (todo.empty()) return PT_OK;
+        // ---- render again what was voided, as many passes as there are flag slots
+        while (!todo.empty() && h->pending.size() + PT_MAX_PIPES < FLAG_RING) {
+            Range &r = todo.back();
+            const uint32_t spp = std::min(h->batch, r.spp);  // (the pass size may have shrunk with the new level sizes)
+            Pipe &pipe = h->pipes[h->passes % h->n_pipes];
+            Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;
+            int rc = run_pass(h, pipe, other, spp, r.first);
+            if (rc) return rc;
+            ++h->passes;
+            r.first += spp;
+            r.spp -= spp;
+            if (r.spp == 0) todo.pop_back();
+        }
+        int rc = sync_pipes(h);
+        if (rc) return rc;
+    }
 }
 
 }  // namespace
@@ -590,6 +653,13 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     if ((rc = dev_alloc(h, &h->d_pixels32, P * 3))) return rc;
     if ((rc = dev_alloc(h, &h->d_pixels8, P * 3))) return rc;
     if ((rc = dev_alloc(h, &h->d_ids, P))) return rc;
+    if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_flags, (size_t)FLAG_RING))) return rc;
+    HIPCHK(h, hipMemset(h->d_flags, 0, FLAG_RING * 4));
+    h->fixed_capacity = h->cfg.branch_capacity != 0;
+    h->growth = h->fixed_capacity ? h->cfg.branch_capacity : 2u;
+    h->flag_cursor = 0;
+    h->pending.clear();
     if ((rc = alloc_levels(h))) return rc;
     h->have_scene = true;
     return ptgpu_clear(h);
@@ -599,6 +669,9 @@ int ptgpu_clear(PtHandle *h) {
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
+    int rc0 = sync_pipes(h);
+    if (rc0) return rc0;
+    h->pending.clear();  // whatever those passes were worth is being thrown away
     const size_t P = (size_t)h->sc.width * h->sc.height;
     HIPCHK(h, hipMemsetAsync(h->d_pixels32, 0, P * 3 * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_pixels8, 0, P * 3, h->stream));
@@ -630,6 +703,10 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
         done += spp;
         h->local_samples += spp;
         h->num_samples += spp;
+        if (h->pending.size() + PT_MAX_PIPES >= FLAG_RING) {  // every flag slot is in use: look at them now
+            if ((rc = sync_pipes(h))) return rc;
+            if ((rc = resolve_pending(h))) return rc;
+        }
         if (h->cfg.profile_events && h->spans.size() > 4096) {
             if ((rc = sync_pipes(h))) return rc;
             if ((rc = drain_spans(h))) return rc;
@@ -648,7 +725,7 @@ int ptgpu_sync(PtHandle *h) {
     if (rc0) return rc0;
     int rc = drain_spans(h);
     if (rc) return rc;
-    if (h->have_scene) return check_overflow(h);
+    if (h->have_scene) return resolve_pending(h);
     return PT_OK;
 }
 
@@ -692,6 +769,8 @@ int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out) 
 int ptgpu_device_pixels32(PtHandle *h, void **device_ptr, uint64_t *n_words) {
     if (!h || !device_ptr) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    int rc = ptgpu_sync(h);
+    if (rc) return rc;
     *device_ptr = h->d_pixels32;
     if (n_words) *n_words = (uint64_t)h->sc.width * h->sc.height * 3;
     return PT_OK;
@@ -706,7 +785,8 @@ int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples) {
 int ptgpu_export_pixels32(PtHandle *h, void *dst_device) {
     if (!h || !dst_device) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
-    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ptgpu_sync(h);
+    if (rc) return rc;
     const size_t bytes = (size_t)h->sc.width * h->sc.height * 3 * 4;
     HIPCHK(h, hipMemcpyAsync(dst_device, h->d_pixels32, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -743,6 +823,7 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         for (int k = 0; k < 8; ++k) out->debug_cycles[k] = c.stamps[k];
         out->records = c.records;
         out->bvh_steps = c.bvh_steps;
+        out->queue_growth = h->has_glass ? h->growth : 1u;
         out->terminal_records = c.terminal;
         out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
     }

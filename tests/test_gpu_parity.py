@@ -298,3 +298,52 @@ def test_every_pipeline_variant_is_bit_exact(binding, oracle, mode, depth):
     assert st["rays"] == rays
     if mode == 3 and depth > 1:
         assert st["records"] < rays  # leaf children were not queued
+
+
+def _glass_scene(w, h):
+    """Nested glass: every primary ray meets glass, and so do most of its children - the queue doubles per level."""
+    sc = S.Scene(image_settings=S.ImageSettings(w, h, True),
+                 camera=S.Camera((0.0, 0.0, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1.0, 1.0 * h / w, 3.0, S.TONE_REINHARD, 1.0, 100.0),
+                 sky=S.Sky.constant((0.8, 0.9, 1.0)))
+    sc.add(S.Sphere((0.0, 0.0, 0.0), 2.0, S.Material.translucent(1.5)))
+    sc.add(S.Sphere((0.3, 0.1, 0.0), 1.0, S.Material.translucent(1.3)))
+    sc.add(S.Sphere((-0.2, -0.1, 0.2), 0.4, S.Material.physically((0.9, 0.4, 0.2), 0.5, 0.0)))
+    sc.add(S.Plane((-1.0, 2.5, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), S.Material.emissive((6.0, 6.0, 6.0))))
+    return sc
+
+
+@pytest.mark.parametrize("pipes", [1, 2])
+def test_levels_grow_and_voided_passes_are_rendered_again(binding, oracle, pipes):
+    """With branch_capacity left at 0 the levels start small (2-fold branching).  Passes that overflow add nothing,
+    the levels are re-allocated larger and exactly those sample ranges are rendered again: the sums, the 8-bit
+    image and the ray count are the oracle's, whichever passes had to be repeated and in whatever order."""
+    sc = _glass_scene(96, 80)
+    depth = 6
+    with binding.PtGpu(max_depth=depth, samples_per_batch=2, concurrent_passes=pipes) as gpu:
+        gpu.upload_scene(sc)
+        before = gpu.stats()
+        assert before["queue_growth"] == 2
+        gpu.render(3)
+        gpu.render(4)
+        p32, n = gpu.read_pixels32()
+        p8 = gpu.read_pixels8()
+        st = gpu.stats()
+        assert n == 7 and st["queue_growth"] > 2 and st["device_bytes"] > before["device_bytes"]
+        gpu.render(2)  # and it keeps working with the grown levels
+        q32, m = gpu.read_pixels32()
+    osc = oracle.OracleScene(sc)
+    r32, r8, rays = osc.render(oracle.options(max_depth=depth), 7)
+    assert np.array_equal(p32, r32) and np.array_equal(p8, r8) and st["rays"] == rays
+    assert m == 9 and np.array_equal(q32, osc.render(oracle.options(max_depth=depth), 9)[0])
+
+
+def test_clear_discards_voided_passes(binding, oracle):
+    sc = _glass_scene(64, 64)
+    with binding.PtGpu(max_depth=6, samples_per_batch=1) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(2)   # overflows at growth 2 (not looked at yet)
+        gpu.clear()     # ... and is thrown away
+        gpu.render(3)
+        p32, n = gpu.read_pixels32()
+    assert n == 3
+    assert np.array_equal(p32, oracle.OracleScene(sc).render(oracle.options(max_depth=6), 3)[0])
