@@ -347,3 +347,16 @@ def test_clear_discards_voided_passes(binding, oracle):
         p32, n = gpu.read_pixels32()
     assert n == 3
     assert np.array_equal(p32, oracle.OracleScene(sc).render(oracle.options(max_depth=6), 3)[0])
+
+
+def test_more_passes_than_flag_slots_between_synchronisations(binding, oracle):
+    """1100 one-sample passes in a single render call: the ring of per-pass overflow flags (1024) is read and
+    reused on the way."""
+    sc = _glass_scene(32, 24)
+    with binding.PtGpu(max_depth=5, samples_per_batch=1, concurrent_passes=2) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(1100)
+        p32, n = gpu.read_pixels32()
+        st = gpu.stats()
+    r32, _, rays = oracle.OracleScene(sc).render(oracle.options(max_depth=5), 1100, threads=8)
+    assert n == 1100 and np.array_equal(p32, r32) and st["rays"] == rays
