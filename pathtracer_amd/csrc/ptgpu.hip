@@ -329,6 +329,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     const uint32_t flat_grid = (uint32_t)std::min<uint64_t>(8192, (S + BLOCK - 1) / BLOCK);
     const size_t lds = h->lds_bytes;
     // kernels that walk the BVH index a per-thread spill area sized for BVH_TRAV_BLOCKS blocks
+    const bool bvh = sc.bvh_nodes != nullptr;
     const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
     HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
@@ -360,15 +361,23 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         } else if (h->fused) {
             Span s(h, PT_KERNEL_TRACE_SHADE, st);
             if (h->regroup) {
-                if (l == 0) k_shade_sorted<true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-                else k_shade_sorted<false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
-            } else {
-                if (h->lds_scene) {
-                    if (l == 0) k_shade<true, true, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-                    else k_shade<true, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                if (bvh) {
+                    if (l == 0) k_shade_sorted<true, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade_sorted<false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
                 } else {
-                    if (l == 0) k_shade<true, true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
-                    else k_shade<true, false, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                    if (l == 0) k_shade_sorted<true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade_sorted<false, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                }
+            } else {
+                if (bvh) {  // (lds_scene is off with a BVH)
+                    if (l == 0) k_shade<true, true, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                } else if (h->lds_scene) {
+                    if (l == 0) k_shade<true, true, true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                } else {
+                    if (l == 0) k_shade<true, true, false, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, false, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
                 }
             }
         } else {
@@ -378,14 +387,15 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
                 else k_trace<<<TG, BLOCK, lds, st>>>(sc, L);
             }
             Span s(h, PT_KERNEL_SHADE, st);
-            if (h->lds_scene) k_shade<false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
-            else k_shade<false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            if (h->lds_scene) k_shade<false, false, true, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            else k_shade<false, false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         }
     }
     {
         Span s(h, PT_KERNEL_TERMINAL, st);
-        k_terminal<<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1],
-                                                   pipe.d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE);
+        uint32_t *shadow_row = pipe.d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE;
+        if (bvh) k_terminal<true><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
+        else k_terminal<false><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
     }
     for (int l = D - 1; l >= 1; --l) {
         Span s(h, PT_KERNEL_GATHER, st);
@@ -644,7 +654,7 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     }
     // auto: BVH scenes run intersection as its own kernel (dynamic ray fetch), small scenes fuse it with shading
     h->fused = h->cfg.fuse_trace_shade < 0 ? (sc.bvh_nodes == nullptr) : (h->cfg.fuse_trace_shade != 0);
-    h->lds_scene = lds_scene_fits(sc.n_sph, sc.n_pl);
+    h->lds_scene = sc.bvh_nodes == nullptr && lds_scene_fits(sc.n_sph, sc.n_pl);
     h->regroup = h->cfg.fuse_trace_shade == 2;  // measured no faster than the plain fused kernel: opt-in only
     h->ahead = h->cfg.fuse_trace_shade == 3 && sc.bvh_nodes == nullptr;
 
@@ -759,7 +769,9 @@ int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out) 
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
     const uint32_t n = h->sc.width * h->sc.height;
-    k_primary_ids<<<std::min<uint32_t>(BVH_TRAV_BLOCKS, (n + BLOCK - 1) / BLOCK), BLOCK, h->lds_bytes, h->stream>>>(h->pipes[0].sc, sample_index, h->d_ids);
+    const uint32_t id_blocks = std::min<uint32_t>(BVH_TRAV_BLOCKS, (n + BLOCK - 1) / BLOCK);
+    if (h->sc.bvh_nodes) k_primary_ids<true><<<id_blocks, BLOCK, h->lds_bytes, h->stream>>>(h->pipes[0].sc, sample_index, h->d_ids);
+    else k_primary_ids<false><<<id_blocks, BLOCK, h->lds_bytes, h->stream>>>(h->pipes[0].sc, sample_index, h->d_ids);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, h->d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
