@@ -33,7 +33,9 @@ constexpr int CSTRIDE = 32;  // u32 words between two shard counters: one 128-by
                              // line serialise (~90/us) no matter which word of it they hit
 constexpr int BLOCK = 256;
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4  // minimum waves per SIMD the shade kernel is compiled for (bounds its VGPR budget)
+#define PT_SHADE_WAVES 6  // waves per SIMD the shade kernel is compiled for (bounds its VGPR budget).  Measured on the sample
+                          // scene, fused kernel ms per 16 steps: 5 waves (89-95 VGPRs, no spill) 100.5, 6 (79, 36-44 B of scratch)
+                          // 95.3, 7 (72, 72 B) 96.4, 8 (64, 124 B) 131.8
 #endif
 
 struct Level {
@@ -391,7 +393,7 @@ __host__ __device__ inline bool lds_scene_fits(uint32_t n_sph, uint32_t n_pl) { 
 // Wave-granular kernel: each wave takes 64 consecutive records.  FUSED: intersection here as well; RAYGEN: level 0
 // generates its primary rays in place; LDS_SCENE: see above (the host checks lds_scene_fits).
 template <bool FUSED, bool RAYGEN, bool LDS_SCENE, bool BVH>
-__global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
+__global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
     DevScene lsc = sc;  // what the shading step reads
@@ -429,7 +431,9 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
         float4 ra_next = make_float4(0.f, 0.f, 0.f, 0.f), rb_next = ra_next;
         if (w_next < m.total) {
             valid_next = tile_record(m, L, w_next, i_next);
+#ifndef PT_NO_PREFETCH
             if (!RAYGEN && valid_next) { ra_next = L.rayA[i_next]; rb_next = L.rayB[i_next]; }
+#endif
         }
         V3 o = v3(0.f, 0.f, 0.f), d = o;
         uint32_t skey = 0, node = 0, prim = MISS;
@@ -463,6 +467,9 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade(DevScene sc, Le
 #endif
         PT_STAMP(6);  // child stores
         w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next;
+#ifdef PT_NO_PREFETCH
+        if (!RAYGEN && valid) { ra = L.rayA[i]; rb = L.rayB[i]; }
+#endif
     }
 #ifdef PT_STAMPS
     if (lane_id() == 0) for (int k = 0; k < 8; ++k) if (stamp_acc[k]) atomicAdd(&ctr->stamps[k], stamp_acc[k]);
