@@ -217,7 +217,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
 constexpr uint32_t DYN_TILES = PT_DYN_TILES;   // wave-tiles (of 64 records) per chunk
 constexpr int DYN_STEPS = PT_DYN_STEPS;        // traversal steps between refill checks
 
-__global__ __launch_bounds__(BLOCK) void k_trace_dyn(DevScene sc, Level L, Counters *ctr) {
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 6  // measured on the quad field: 5 waves per SIMD (89 VGPRs) 3670, 6 (80, 52 B scratch) 3850, 7 (72, 84 B) 3180 Mrays/s
+#endif
+__global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc, Level L, Counters *ctr) {
     __shared__ uint32_t s_incl[NSHARD], s_cnt[NSHARD];
     TileMap m = tile_map(L);
     if (threadIdx.x < NSHARD) { s_incl[threadIdx.x] = m.incl; s_cnt[threadIdx.x] = m.cnt; }
