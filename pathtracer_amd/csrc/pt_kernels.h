@@ -39,18 +39,25 @@ constexpr int BLOCK = 256;
 #endif
 
 struct Level {
-    float4 *rayA;       // (origin.xyz, dir.x)
-    float4 *rayB;       // (dir.y, dir.z, bits(sample id), bits(path node))
-    uint32_t *parent;   // (parent record index << 1) | child slot
-    uint32_t *hitprim;  // nearest hit: primitive id | HIT_OUT_BIT if Transition::Out, or MISS (two-kernel pipeline only)
-    float *hit_t;       // its distance (two-kernel pipeline only)
-    uint32_t *meta;     // node kind
-    float4 *coef;       // node coefficients (xyz, w)
-    float4 *val0;       // radiance of child 0
-    float4 *val1;       // radiance of child 1 (glass reflection)
+    // One allocation per level, carved into SoA arrays of n = NSHARD * shard_cap records: the five 16-byte arrays
+    // first, then the four 4-byte ones.  Only the base is passed to the kernels (three Levels of ten pointers each
+    // cost 60 scalar registers and pushed the fused kernel into spilling them); the accessors below rebuild the
+    // array addresses with a few scalar instructions.
+    char *base;
     uint32_t *count;    // [NSHARD * CSTRIDE] records per shard, shard q at count[q * CSTRIDE]
     uint32_t *overflow; // this pass's flag: set when an append found a level full (the pass is then not accumulated)
     uint32_t shard_cap;
+    PT_HD size_t n() const { return (size_t)shard_cap * 64u; }  // NSHARD = 64
+    PT_HD float4 *rayA() const { return reinterpret_cast<float4 *>(base); }                  // (origin.xyz, dir.x)
+    PT_HD float4 *rayB() const { return reinterpret_cast<float4 *>(base + 16 * n()); }       // (dir.y, dir.z, bits(rng key), bits(path node))
+    PT_HD float4 *coef() const { return reinterpret_cast<float4 *>(base + 32 * n()); }       // node coefficients (xyz, w)
+    PT_HD float4 *val0() const { return reinterpret_cast<float4 *>(base + 48 * n()); }       // radiance of child 0
+    PT_HD float4 *val1() const { return reinterpret_cast<float4 *>(base + 64 * n()); }       // radiance of child 1 (glass reflection)
+    PT_HD uint32_t *parent() const { return reinterpret_cast<uint32_t *>(base + 80 * n()); } // (parent record index << 1) | child slot
+    PT_HD uint32_t *hitprim() const { return reinterpret_cast<uint32_t *>(base + 84 * n()); } // nearest hit: primitive id | HIT_OUT_BIT if Transition::Out, or MISS
+    PT_HD float *hit_t() const { return reinterpret_cast<float *>(base + 88 * n()); }        // its distance (with hitprim: two-kernel and trace-ahead pipelines)
+    PT_HD uint32_t *meta() const { return reinterpret_cast<uint32_t *>(base + 92 * n()); }   // node kind
+    static constexpr size_t RECORD_BYTES = 96;
 };
 
 struct PassParams {
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, Level L0, PassPar
         V3 o, d;
         uint32_t skey;
         primary_ray(sc, pp, i, o, d, skey);
-        L0.rayA[i] = make_float4(o.x, o.y, o.z, d.x);
-        L0.rayB[i] = make_float4(d.y, d.z, u2f(skey), u2f(1u));
+        L0.rayA()[i] = make_float4(o.x, o.y, o.z, d.x);
+        L0.rayB()[i] = make_float4(d.y, d.z, u2f(skey), u2f(1u));
     }
 }
 
@@ -192,12 +199,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         if (!tile_record(m, L, w, i)) continue;
-        float4 a = L.rayA[i], b = L.rayB[i];
+        float4 a = L.rayA()[i], b = L.rayB()[i];
         float t;
         int tr;
         uint32_t prim = nearest_hit<false>(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), t, tr);  // (BVH scenes use k_trace_dyn)
-        L.hitprim[i] = pack_hit(prim, tr);
-        L.hit_t[i] = t;
+        L.hitprim()[i] = pack_hit(prim, tr);
+        L.hit_t()[i] = t;
     }
 }
 
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
                 uint32_t off = (w - before) * 64u + (k & 63u);
                 if (off < s_cnt[lo]) {
                     rec = lo * L.shard_cap + off;
-                    float4 a = L.rayA[rec], b = L.rayB[rec];
+                    float4 a = L.rayA()[rec], b = L.rayB()[rec];
                     bvh_begin(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), st);
                     active = true;
 #ifdef PT_TRAV_STATS
@@ -286,8 +293,8 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #endif
                 my_steps += bvh_step(sc, st, stk);
                 if (st.node == BVH_EMPTY) {
-                    L.hitprim[rec] = pack_hit(st.best, st.best_out);
-                    L.hit_t[rec] = st.best_t;
+                    L.hitprim()[rec] = pack_hit(st.best, st.best_out);
+                    L.hit_t()[rec] = st.best_t;
                     active = false;
                 }
             }
@@ -326,7 +333,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
     const uint32_t nkey = rng_node_key(skey, node);
     uint32_t par = 0;
     if (valid) {
-        if (level != 0) par = L.parent[i];
+        if (level != 0) par = L.parent()[i];
         shade_prepare(sc, o, d, prim, hit_t, hit_transition, nkey, c);
     }
     bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
@@ -339,8 +346,8 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
         if (has1 && !terminal_sample(sc, c.o1, rng_node_key(skey, 2u * node + 1u), dir, dist, rad)) has1 = false;
         folded = had0 && !has0 && !has1;
         if (!folded) {  // (a glass node with one child black and the other queued)
-            if (had0 && !has0) L.val0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (had1 && !has1) L.val1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (had0 && !has0) L.val0()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (had1 && !has1) L.val1()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     PT_STAMP(2);  // hit rebuild, material fetch, arm decision, terminal culling
@@ -360,29 +367,29 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
         }
         if (out.kind == NK_LEAF) {
             if (level == 0) {
-                L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
+                L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
             } else {
                 float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
-                if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+                if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
             }
         } else {
-            L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.coef_w);
+            L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.coef_w);
         }
-        L.meta[i] = out.kind;
+        L.meta()[i] = out.kind;
     }
     PT_STAMP(4);  // sampling / BRDF arithmetic + node stores
     uint32_t i0, i1;
     wave_resolve(Lnext, shard, rsv, has0, has1, i0, i1, ctr);
     PT_STAMP(5);
     if (has0) {
-        Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
-        Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
-        Lnext.parent[i0] = (i << 1);
+        Lnext.rayA()[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
+        Lnext.rayB()[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
+        Lnext.parent()[i0] = (i << 1);
     }
     if (has1) {
-        Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
-        Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
-        Lnext.parent[i1] = (i << 1) | 1u;
+        Lnext.rayA()[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
+        Lnext.rayB()[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
+        Lnext.parent()[i1] = (i << 1) | 1u;
     }
 }
 
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevSc
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     if (w < m.total) {
         valid = tile_record(m, L, w, i);
-        if (!RAYGEN && valid) { ra = L.rayA[i]; rb = L.rayB[i]; }
+        if (!RAYGEN && valid) { ra = L.rayA()[i]; rb = L.rayB()[i]; }
     }
     while (w < m.total) {
         const uint32_t w_next = w + waves_in_grid();
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevSc
         if (w_next < m.total) {
             valid_next = tile_record(m, L, w_next, i_next);
 #ifndef PT_NO_PREFETCH
-            if (!RAYGEN && valid_next) { ra_next = L.rayA[i_next]; rb_next = L.rayB[i_next]; }
+            if (!RAYGEN && valid_next) { ra_next = L.rayA()[i_next]; rb_next = L.rayB()[i_next]; }
 #endif
         }
         V3 o = v3(0.f, 0.f, 0.f), d = o;
@@ -456,8 +463,8 @@ __global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevSc
         if (valid) {
             if (FUSED) prim = nearest_hit<BVH>(sc, o, d, hit_t, hit_tr);
             else {  // the trace kernel left the winner, its Transition and its distance
-                uint32_t word = L.hitprim[i];
-                hit_t = L.hit_t[i];
+                uint32_t word = L.hitprim()[i];
+                hit_t = L.hit_t()[i];
                 prim = word == MISS ? MISS : (word & ~HIT_OUT_BIT);
                 hit_tr = (word != MISS && (word & HIT_OUT_BIT)) ? 1 : 0;
             }
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevSc
         PT_STAMP(6);  // child stores
         w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next;
 #ifdef PT_NO_PREFETCH
-        if (!RAYGEN && valid) { ra = L.rayA[i]; rb = L.rayB[i]; }
+        if (!RAYGEN && valid) { ra = L.rayA()[i]; rb = L.rayB()[i]; }
 #endif
     }
 #ifdef PT_STAMPS
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
     float rt = 0.0f;
     if (w < m.total) {
         valid = tile_record(m, L, w, i);
-        if (!RAYGEN && valid) { ra = L.rayA[i]; rb = L.rayB[i]; rp = L.hitprim[i]; rt = L.hit_t[i]; }
+        if (!RAYGEN && valid) { ra = L.rayA()[i]; rb = L.rayB()[i]; rp = L.hitprim()[i]; rt = L.hit_t()[i]; }
     }
     while (w < m.total) {
         const uint32_t w_next = w + waves_in_grid();
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
         float rt_next = 0.0f;
         if (w_next < m.total) {
             valid_next = tile_record(m, L, w_next, i_next);
-            if (!RAYGEN && valid_next) { ra_next = L.rayA[i_next]; rb_next = L.rayB[i_next]; rp_next = L.hitprim[i_next]; rt_next = L.hit_t[i_next]; }
+            if (!RAYGEN && valid_next) { ra_next = L.rayA()[i_next]; rb_next = L.rayB()[i_next]; rp_next = L.hitprim()[i_next]; rt_next = L.hit_t()[i_next]; }
         }
         V3 o = v3(0.f, 0.f, 0.f), d = o;
         uint32_t skey = 0, node = 0, prim = MISS;
@@ -572,8 +579,8 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
             shade_prepare(lsc, o, d, prim, hit_t, hit_tr, nkey, c);
             shade_finish(c, d, nkey, out);
             // (only a primary ray can be a leaf here; the resolve step reads its radiance from coef)
-            L.coef[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.kind == NK_LEAF ? 0.0f : out.coef_w);
-            L.meta[i] = out.kind;
+            L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.kind == NK_LEAF ? 0.0f : out.coef_w);
+            L.meta()[i] = out.kind;
         }
         bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
         uint32_t hp0 = MISS, hp1 = MISS;
@@ -583,11 +590,11 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
             V3 dir, rad;
             float dist;
             if (has0 && !terminal_sample(sc, c.o0, rng_node_key(skey, 2u * node), dir, dist, rad)) {
-                L.val0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                L.val0()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 has0 = false;
             }
             if (has1 && !terminal_sample(sc, c.o1, rng_node_key(skey, 2u * node + 1u), dir, dist, rad)) {
-                L.val1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                L.val1()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 has1 = false;
             }
         } else {
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
                     const bool leaf = child_is_leaf(sc, lsc, p, cd, value);
                     if (leaf) {
                         float4 v = make_float4(value.x, value.y, value.z, 0.0f);
-                        if (slot == 0) L.val0[i] = v; else L.val1[i] = v;
+                        if (slot == 0) L.val0()[i] = v; else L.val1()[i] = v;
                     }
                     if (slot == 0) { has0 = !leaf; hp0 = pack_hit(p, tr); t0 = ct; }
                     else { has1 = !leaf; hp1 = pack_hit(p, tr); t1 = ct; }
@@ -617,16 +624,16 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
         uint32_t i0, i1;
         wave_resolve(Lnext, shard, rsv, has0, has1, i0, i1, ctr);
         if (has0) {
-            Lnext.rayA[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
-            Lnext.rayB[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
-            Lnext.parent[i0] = (i << 1);
-            if (!last_traced) { Lnext.hitprim[i0] = hp0; Lnext.hit_t[i0] = t0; }
+            Lnext.rayA()[i0] = make_float4(out.o0.x, out.o0.y, out.o0.z, out.d0.x);
+            Lnext.rayB()[i0] = make_float4(out.d0.y, out.d0.z, u2f(skey), u2f(2u * node));
+            Lnext.parent()[i0] = (i << 1);
+            if (!last_traced) { Lnext.hitprim()[i0] = hp0; Lnext.hit_t()[i0] = t0; }
         }
         if (has1) {
-            Lnext.rayA[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
-            Lnext.rayB[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
-            Lnext.parent[i1] = (i << 1) | 1u;
-            if (!last_traced) { Lnext.hitprim[i1] = hp1; Lnext.hit_t[i1] = t1; }
+            Lnext.rayA()[i1] = make_float4(out.o1.x, out.o1.y, out.o1.z, out.d1.x);
+            Lnext.rayB()[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
+            Lnext.parent()[i1] = (i << 1) | 1u;
+            if (!last_traced) { Lnext.hitprim()[i1] = hp1; Lnext.hit_t()[i1] = t1; }
         }
         w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next; rp = rp_next; rt = rt_next;
     }
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene
                 primary_ray(sc, pp, i, o, d, skey);
                 node = 1u;
             } else {
-                float4 a = L.rayA[i], b = L.rayB[i];
+                float4 a = L.rayA()[i], b = L.rayB()[i];
                 o = v3(a.x, a.y, a.z); d = v3(a.w, b.x, b.y);
                 skey = f2u(b.z);
                 node = f2u(b.w);
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
         bool valid = tile_record(m, L, w, i);
         bool shadow = false;
         if (valid) {
-            float4 a = L.rayA[i], b = L.rayB[i];
+            float4 a = L.rayA()[i], b = L.rayB()[i];
             V3 o = v3(a.x, a.y, a.z);
             uint32_t nkey = rng_node_key(f2u(b.z), f2u(b.w));
             V3 value = v3(0.0f, 0.0f, 0.0f), dir, radiance;
@@ -741,9 +748,9 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
                 uint32_t prim = nearest_hit<BVH>(sc, o, dir, t);
                 if (prim != MISS && t > dist - 0.000001f) value = radiance;
             }
-            uint32_t par = L.parent[i];
+            uint32_t par = L.parent()[i];
             float4 v = make_float4(value.x, value.y, value.z, 0.0f);
-            if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+            if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
         }
         n_shadow += (uint32_t)__popcll(__ballot(shadow));
     }
@@ -756,15 +763,15 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         if (!tile_record(m, L, w, i)) continue;
-        uint32_t kind = L.meta[i];
+        uint32_t kind = L.meta()[i];
         if (kind == NK_LEAF) continue;
-        float4 c = L.coef[i], a = L.val0[i];
+        float4 c = L.coef()[i], a = L.val0()[i];
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kind == NK_GLASS) b = L.val1[i];
+        if (kind == NK_GLASS) b = L.val1()[i];
         V3 value = node_value(kind, v3(c.x, c.y, c.z), c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
-        uint32_t par = L.parent[i];
+        uint32_t par = L.parent()[i];
         float4 v = make_float4(value.x, value.y, value.z, 0.0f);
-        if (par & 1u) Lprev.val1[par >> 1] = v; else Lprev.val0[par >> 1] = v;
+        if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
     }
 }
 
@@ -786,11 +793,11 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassPa
         for (uint32_t s = 0; s < spp; ++s) {
             uint32_t i = s * pp.n_pixels + pixel;
             // all three loads are issued before any is consumed (val0 of a leaf is never written: ignored below)
-            uint32_t kind = L0.meta[i];
-            float4 c = L0.coef[i];
-            float4 a = L0.val0[i];
+            uint32_t kind = L0.meta()[i];
+            float4 c = L0.coef()[i];
+            float4 a = L0.val0()[i];
             float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kind == NK_GLASS) b = L0.val1[i];
+            if (kind == NK_GLASS) b = L0.val1()[i];
             V3 value = v3(c.x, c.y, c.z);
             if (kind != NK_LEAF) value = node_value(kind, value, c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
             uint32_t q[3];

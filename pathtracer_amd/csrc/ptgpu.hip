@@ -247,7 +247,7 @@ int alloc_levels(PtHandle *h) {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
-    const uint64_t rec_bytes = 16 + 16 + 4 + 4 + 4 + 4 + 16 + 16 + 16;
+    const uint64_t rec_bytes = Level::RECORD_BYTES;
     const uint64_t budget = 48ull << 30;
     for (;;) {
         uint64_t total = 0;
@@ -290,15 +290,7 @@ int alloc_levels(PtHandle *h) {
             h->device_bytes += bytes;
             h->level_bytes += bytes;
             pipe.level_allocs.push_back(base);
-            L.rayA = (float4 *)base; base += n * 16;
-            L.rayB = (float4 *)base; base += n * 16;
-            L.coef = (float4 *)base; base += n * 16;
-            L.val0 = (float4 *)base; base += n * 16;
-            L.val1 = (float4 *)base; base += n * 16;
-            L.parent = (uint32_t *)base; base += n * 4;
-            L.hitprim = (uint32_t *)base; base += n * 4;
-            L.hit_t = (float *)base; base += n * 4;
-            L.meta = (uint32_t *)base;
+            L.base = base;
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_shard_caps, caps.data(), caps.size() * 4, hipMemcpyHostToDevice, h->stream));
