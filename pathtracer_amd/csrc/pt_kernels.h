@@ -331,9 +331,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
     ShadeCtx c;
     c.n_children = 0;
     const uint32_t nkey = rng_node_key(skey, node);
-    uint32_t par = 0;
     if (valid) {
-        if (level != 0) par = L.parent()[i];
         shade_prepare(sc, o, d, prim, hit_t, hit_transition, nkey, c);
     }
     bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
@@ -369,6 +367,8 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
             if (level == 0) {
                 L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
             } else {
+                // (the parent link is fetched only here: in closed scenes few records are leaves)
+                const uint32_t par = L.parent()[i];
                 float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
                 if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
             }
