@@ -311,6 +311,20 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #endif
 }
 
+// The resolve step PULLS the radiance of a level-0 node's children out of their level-1 records (it evaluates the
+// level-1 node itself) instead of having a backward-sweep launch push it into level 0 first: that launch, the
+// largest of the sweep, and a 16-byte write plus read per sample go away.  For that a level-0 record remembers where
+// its children were queued, in two arrays it has no other use for (it has no parent, and its hit is consumed by
+// then).  NO_CHILD: the child's radiance is in this record's own val slot (a black or terminal light sample).
+constexpr uint32_t NO_CHILD = 0xFFFFFFFFu;
+__device__ __forceinline__ void remember_children(const Level &L0, uint32_t i, uint32_t kind, uint32_t last_traced, bool has0, bool has1,
+                                                  uint32_t i0, uint32_t i1) {
+    if (kind == NK_LEAF) return;
+    const bool pull = !last_traced;  // (with max_depth 1 the children are terminal samples: k_terminal pushes)
+    L0.parent()[i] = (pull && has0) ? i0 : NO_CHILD;
+    if (kind == NK_GLASS) L0.hitprim()[i] = (pull && has1) ? i1 : NO_CHILD;
+}
+
 // ---- shade: reference src/tracer.rs:494-583 ----------------------------------------------------------------------
 // One record of level `level`: material switch, node coefficients, children appended to Lnext (level + 1).
 // At level >= 1 a leaf stores its radiance straight into its parent's val slot; at level 0 it keeps it in its own
@@ -364,7 +378,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
             out.kind = NK_LEAF;
         }
         if (out.kind == NK_LEAF) {
-            if (level == 0) {
+            if (level <= 1) {  // levels 0 and 1 are read by the resolve step, which takes a leaf's radiance from coef
                 L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
             } else {
                 // (the parent link is fetched only here: in closed scenes few records are leaves)
@@ -391,6 +405,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
         Lnext.rayB()[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
         Lnext.parent()[i1] = (i << 1) | 1u;
     }
+    if (level == 0 && valid) remember_children(L, i, out.kind, last_traced, has0, has1, i0, i1);
 }
 
 // Small scenes keep their primitive and material tables in LDS for the shading step: there every lane fetches the
@@ -635,6 +650,7 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
             Lnext.parent()[i1] = (i << 1) | 1u;
             if (!last_traced) { Lnext.hitprim()[i1] = hp1; Lnext.hit_t()[i1] = t1; }
         }
+        if (RAYGEN && valid) remember_children(L, i, out.kind, last_traced, has0, has1, i0, i1);
         w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next; rp = rp_next; rt = rt_next;
     }
     if (n_traced != 0 && lane_id() == 0) atomicAdd(&traced_count[shard * CSTRIDE], n_traced);
@@ -778,7 +794,27 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
 // ---- resolve: reference src/tracer.rs:634-643 (tone map, gamma, Pixel32::from_unit, add_pixel32) --------------------------
 // One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + pixel) into
 // its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
-__global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassParams pp, uint32_t spp, uint32_t *pixels32) {
+// Radiance of child `slot` of level-0 record i: pulled from its level-1 record (leaf: coef; inner node: node_value of
+// its coefficients and its own children's radiance, exactly what the backward sweep would have pushed), or read from
+// the record's own val slot when the child was never queued.
+__device__ __forceinline__ V3 child_radiance(const Level &L0, const Level &L1, uint32_t i, int slot, bool pull) {
+    uint32_t c = NO_CHILD;
+    if (pull) c = slot ? L0.hitprim()[i] : L0.parent()[i];
+    if (c == NO_CHILD) {
+        float4 v = slot ? L0.val1()[i] : L0.val0()[i];
+        return v3(v.x, v.y, v.z);
+    }
+    uint32_t kind = L1.meta()[c];
+    float4 k = L1.coef()[c];
+    if (kind == NK_LEAF) return v3(k.x, k.y, k.z);
+    float4 a = L1.val0()[c];
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kind == NK_GLASS) b = L1.val1()[c];
+    return node_value(kind, v3(k.x, k.y, k.z), k.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level L1, PassParams pp, uint32_t spp, uint32_t pull,
+                                                  uint32_t *pixels32) {
     if (*L0.overflow != 0u) return;  // a level overflowed somewhere in this pass: it adds nothing (the host repeats it)
     // the quantiser's threshold table is searched 24 times per sample with per-lane indices: keep it in LDS
     __shared__ float s_gamma[256];
@@ -792,14 +828,15 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, PassPa
 #pragma unroll 2
         for (uint32_t s = 0; s < spp; ++s) {
             uint32_t i = s * pp.n_pixels + pixel;
-            // all three loads are issued before any is consumed (val0 of a leaf is never written: ignored below)
             uint32_t kind = L0.meta()[i];
             float4 c = L0.coef()[i];
-            float4 a = L0.val0()[i];
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kind == NK_GLASS) b = L0.val1()[i];
             V3 value = v3(c.x, c.y, c.z);
-            if (kind != NK_LEAF) value = node_value(kind, value, c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+            if (kind != NK_LEAF) {
+                V3 a = child_radiance(L0, L1, i, 0, pull != 0u);
+                V3 b = v3(0.f, 0.f, 0.f);
+                if (kind == NK_GLASS) b = child_radiance(L0, L1, i, 1, pull != 0u);
+                value = node_value(kind, value, c.w, a, b);
+            }
             uint32_t q[3];
             tonemap_gamma_quantise(sc, value, q);
             acc0 += q[0]; acc1 += q[1]; acc2 += q[2];

@@ -389,7 +389,8 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         if (bvh) k_terminal<true><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
         else k_terminal<false><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
     }
-    for (int l = D - 1; l >= 1; --l) {
+    // (level 1 is not swept when it is a traced level: the resolve step pulls from it)
+    for (int l = D - 1; l >= (D >= 2 ? 2 : 1); --l) {
         Span s(h, PT_KERNEL_GATHER, st);
         k_gather<<<GRID_TILES, BLOCK, 0, st>>>(levels[l], levels[l - 1]);
     }
@@ -397,7 +398,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     if (other && other->resolved_pending) HIPCHK(h, hipStreamWaitEvent(st, other->resolved, 0));
     {
         Span s(h, PT_KERNEL_RESOLVE, st);
-        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], pp, spp, h->d_pixels32);
+        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], levels[1], pp, spp, D >= 2 ? 1u : 0u, h->d_pixels32);
     }
     k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
     HIPCHK(h, hipGetLastError());
