@@ -311,18 +311,42 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #endif
 }
 
-// The resolve step PULLS the radiance of a level-0 node's children out of their level-1 records (it evaluates the
-// level-1 node itself) instead of having a backward-sweep launch push it into level 0 first: that launch, the
-// largest of the sweep, and a 16-byte write plus read per sample go away.  For that a level-0 record remembers where
-// its children were queued, in two arrays it has no other use for (it has no parent, and its hit is consumed by
-// then).  NO_CHILD: the child's radiance is in this record's own val slot (a black or terminal light sample).
+// The backward sweep works on PAIRS of levels.  A node of an even level PULLS the radiance of its children out of
+// their records one level up (it evaluates that odd-level node itself: leaf -> its coef, inner node -> node_value of
+// its coefficients and ITS children's radiance) and hands its own radiance down: level 0 to the pixel (the resolve
+// step), levels 2, 4, ... into their parent's val slot.  Odd levels therefore need no launch of their own, and the
+// 16-byte write plus read per record that pushing through them would cost go away.  For that
+//   * a leaf of an odd level keeps its radiance in its own coef instead of pushing it down,
+//   * a record of an even level remembers where its children were queued, in the two arrays that held its hit
+//     (consumed by then; unused in the fused pipeline).  NO_CHILD: the child's radiance is in this record's own val
+//     slot (a black terminal light sample, a leaf child of the trace-ahead pipeline, or children on the last level,
+//     which k_terminal pushes).
 constexpr uint32_t NO_CHILD = 0xFFFFFFFFu;
-__device__ __forceinline__ void remember_children(const Level &L0, uint32_t i, uint32_t kind, uint32_t last_traced, bool has0, bool has1,
+__device__ __forceinline__ bool pulled_level(uint32_t level) { return (level & 1u) != 0u; }
+__device__ __forceinline__ void remember_children(const Level &L, uint32_t i, uint32_t kind, uint32_t last_traced, bool has0, bool has1,
                                                   uint32_t i0, uint32_t i1) {
     if (kind == NK_LEAF) return;
-    const bool pull = !last_traced;  // (with max_depth 1 the children are terminal samples: k_terminal pushes)
-    L0.parent()[i] = (pull && has0) ? i0 : NO_CHILD;
-    if (kind == NK_GLASS) L0.hitprim()[i] = (pull && has1) ? i1 : NO_CHILD;
+    const bool pull = !last_traced;  // (children on the last level are terminal samples: k_terminal pushes)
+    L.hitprim()[i] = (pull && has0) ? i0 : NO_CHILD;
+    if (kind == NK_GLASS) L.hit_t()[i] = u2f((pull && has1) ? i1 : NO_CHILD);
+}
+
+// Radiance of child `slot` of record i of an even level: pulled from its record one level up, or read from the
+// record's own val slot when the child was never queued there.
+__device__ __forceinline__ V3 child_radiance(const Level &L, const Level &Lup, uint32_t i, int slot, bool pull) {
+    uint32_t c = NO_CHILD;
+    if (pull) c = slot ? f2u(L.hit_t()[i]) : L.hitprim()[i];
+    if (c == NO_CHILD) {
+        float4 v = slot ? L.val1()[i] : L.val0()[i];
+        return v3(v.x, v.y, v.z);
+    }
+    uint32_t kind = Lup.meta()[c];
+    float4 k = Lup.coef()[c];
+    if (kind == NK_LEAF) return v3(k.x, k.y, k.z);
+    float4 a = Lup.val0()[c];
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kind == NK_GLASS) b = Lup.val1()[c];
+    return node_value(kind, v3(k.x, k.y, k.z), k.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
 }
 
 // ---- shade: reference src/tracer.rs:494-583 ----------------------------------------------------------------------
@@ -378,7 +402,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
             out.kind = NK_LEAF;
         }
         if (out.kind == NK_LEAF) {
-            if (level <= 1) {  // levels 0 and 1 are read by the resolve step, which takes a leaf's radiance from coef
+            if (level == 0 || pulled_level(level)) {  // read where it is: by the resolve step, or by the level below
                 L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
             } else {
                 // (the parent link is fetched only here: in closed scenes few records are leaves)
@@ -405,7 +429,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
         Lnext.rayB()[i1] = make_float4(out.d1.y, out.d1.z, u2f(skey), u2f(2u * node + 1u));
         Lnext.parent()[i1] = (i << 1) | 1u;
     }
-    if (level == 0 && valid) remember_children(L, i, out.kind, last_traced, has0, has1, i0, i1);
+    if (!pulled_level(level) && valid) remember_children(L, i, out.kind, last_traced, has0, has1, i0, i1);
 }
 
 // Small scenes keep their primitive and material tables in LDS for the shading step: there every lane fetches the
@@ -650,7 +674,7 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
             Lnext.parent()[i1] = (i << 1) | 1u;
             if (!last_traced) { Lnext.hitprim()[i1] = hp1; Lnext.hit_t()[i1] = t1; }
         }
-        if (RAYGEN && valid) remember_children(L, i, out.kind, last_traced, has0, has1, i0, i1);
+        if (!pulled_level(level) && valid) remember_children(L, i, out.kind, last_traced, has0, has1, i0, i1);
         w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next; rp = rp_next; rt = rt_next;
     }
     if (n_traced != 0 && lane_id() == 0) atomicAdd(&traced_count[shard * CSTRIDE], n_traced);
@@ -773,18 +797,21 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
     if (n_shadow != 0 && lane_id() == 0) atomicAdd(&shadow_count[my_shard() * CSTRIDE], n_shadow);
 }
 
-// ---- backward sweep: inner nodes of level l >= 1 hand their radiance to their parents ------------------------------
-__global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
+// ---- backward sweep: the inner nodes of an even level l >= 2 hand their radiance to their parents -----------------
+// `pull`: level l + 1 is a traced level, so the children's radiance is taken from their records there (see
+// remember_children); otherwise (l is the last traced level) it is in the val slots, put there by k_terminal.
+__global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lprev, uint32_t pull) {
     TileMap m = tile_map(L);
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         if (!tile_record(m, L, w, i)) continue;
         uint32_t kind = L.meta()[i];
         if (kind == NK_LEAF) continue;
-        float4 c = L.coef()[i], a = L.val0()[i];
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kind == NK_GLASS) b = L.val1()[i];
-        V3 value = node_value(kind, v3(c.x, c.y, c.z), c.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
+        float4 c = L.coef()[i];
+        V3 a = child_radiance(L, Lup, i, 0, pull != 0u);
+        V3 b = v3(0.f, 0.f, 0.f);
+        if (kind == NK_GLASS) b = child_radiance(L, Lup, i, 1, pull != 0u);
+        V3 value = node_value(kind, v3(c.x, c.y, c.z), c.w, a, b);
         uint32_t par = L.parent()[i];
         float4 v = make_float4(value.x, value.y, value.z, 0.0f);
         if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
@@ -794,25 +821,6 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lprev) {
 // ---- resolve: reference src/tracer.rs:634-643 (tone map, gamma, Pixel32::from_unit, add_pixel32) --------------------------
 // One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + pixel) into
 // its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
-// Radiance of child `slot` of level-0 record i: pulled from its level-1 record (leaf: coef; inner node: node_value of
-// its coefficients and its own children's radiance, exactly what the backward sweep would have pushed), or read from
-// the record's own val slot when the child was never queued.
-__device__ __forceinline__ V3 child_radiance(const Level &L0, const Level &L1, uint32_t i, int slot, bool pull) {
-    uint32_t c = NO_CHILD;
-    if (pull) c = slot ? L0.hitprim()[i] : L0.parent()[i];
-    if (c == NO_CHILD) {
-        float4 v = slot ? L0.val1()[i] : L0.val0()[i];
-        return v3(v.x, v.y, v.z);
-    }
-    uint32_t kind = L1.meta()[c];
-    float4 k = L1.coef()[c];
-    if (kind == NK_LEAF) return v3(k.x, k.y, k.z);
-    float4 a = L1.val0()[c];
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kind == NK_GLASS) b = L1.val1()[c];
-    return node_value(kind, v3(k.x, k.y, k.z), k.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
-}
-
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level L1, PassParams pp, uint32_t spp, uint32_t pull,
                                                   uint32_t *pixels32) {
     if (*L0.overflow != 0u) return;  // a level overflowed somewhere in this pass: it adds nothing (the host repeats it)

@@ -389,10 +389,11 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         if (bvh) k_terminal<true><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
         else k_terminal<false><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
     }
-    // (level 1 is not swept when it is a traced level: the resolve step pulls from it)
-    for (int l = D - 1; l >= (D >= 2 ? 2 : 1); --l) {
+    // Backward sweep over the even levels, deepest first; each pulls from the odd level above it (when that is a
+    // traced level) and pushes into the odd level below.  With max_depth 1 level 1 holds terminal samples, which push.
+    for (int l = (D - 1) & ~1; l >= 2; l -= 2) {
         Span s(h, PT_KERNEL_GATHER, st);
-        k_gather<<<GRID_TILES, BLOCK, 0, st>>>(levels[l], levels[l - 1]);
+        k_gather<<<GRID_TILES, BLOCK, 0, st>>>(levels[l], levels[l + 1], levels[l - 1], l + 1 <= D - 1 ? 1u : 0u);
     }
     // The accumulator is read-modify-written without atomics: passes add their samples one after the other.
     if (other && other->resolved_pending) HIPCHK(h, hipStreamWaitEvent(st, other->resolved, 0));
