@@ -156,7 +156,7 @@ def main() -> None:
             if name == "trace_shade":
                 # per traced record: read ray 32 (not at level 0: primary rays are generated in the kernel),
                 # write kind 4 + coef-or-leaf-value 16; per appended child: write ray 32 + parent 4
-                # (+ 4 per record of an even level for the child link; priced on every traced record: an upper bound)
+                # (the 4-byte child link written by the records of even levels is not priced)
                 alg = 52.0 * traced - 32.0 * st["samples"] + 36.0 * children
             elif name == "trace":
                 # read ray 32, write prim id 4; BVH: one 64-byte fetch per traversal step (inner node or leaf
