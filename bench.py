@@ -69,6 +69,11 @@ def main() -> None:
     ap.add_argument("--grid", type=int, default=1000, help="quads: rectangles per side")
     ap.add_argument("--fused", type=int, default=-1)
     ap.add_argument("--batch", type=int, default=0, help="samples per pixel per pipeline pass (0 = library default)")
+    ap.add_argument("--passes", type=int, default=-1,
+                    help="pipeline passes in flight; 0 = library default (2); -1 = 1 for sample/room, so that the per-kernel "
+                         "durations of the roofline block are not blurred by a second pass running concurrently (the "
+                         "library default is measured right after the timed region and reported as `pipelined`), "
+                         "library default for quads")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events (no roofline block)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,8 +109,10 @@ def main() -> None:
         depth = args.max_depth or 16
     args.max_depth = depth
     args.spp_per_step = args.spp_per_step or 32
+    if args.passes < 0:
+        args.passes = 0 if args.workload == "quads" else 1
     gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, max_depth=args.max_depth,
-                        fuse_trace_shade=args.fused, samples_per_batch=args.batch, profile_events=0 if args.no_events else 1)
+                        fuse_trace_shade=args.fused, samples_per_batch=args.batch, concurrent_passes=args.passes, profile_events=0 if args.no_events else 1)
     gpu.upload_scene(sc)
     for _ in range(args.warmup):
         gpu.render(args.spp_per_step)
@@ -124,6 +131,25 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
 
     st = gpu.stats()
+    pipelined = None
+    if world == 1 and args.passes == 1 and not os.environ.get("PTGPU_FORCE_COLLECTIVE"):
+        # the same steps with the library's default of two passes in flight (no per-kernel events)
+        gpu.close()
+        gpu = binding.PtGpu(device=local_rank, max_depth=args.max_depth, fuse_trace_shade=args.fused, samples_per_batch=args.batch,
+                            concurrent_passes=0, profile_events=0)
+        gpu.upload_scene(sc)
+        for _ in range(args.warmup):
+            gpu.render(args.spp_per_step)
+        gpu.sync()
+        gpu.clear()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gpu.render(args.spp_per_step)
+        gpu.sync()
+        dt = time.perf_counter() - t1
+        pipelined = {"value": round(gpu.stats()["rays"] / dt / 1e6, 2), "unit": "Mrays/s", "passes_in_flight": 2,
+                     "ms_per_step": round(1e3 * dt / args.steps, 4)}
     agg = torch.tensor([float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -185,6 +211,9 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": round(alg / n_launch, 1),
                 "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
             }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
+        out["config"]["passes_in_flight"] = args.passes if args.passes else 2
         if st["bvh_nodes"]:
             out["bvh"] = {"nodes": st["bvh_nodes"], "leaf_prims": st["bvh_leaf_prims"],
                           "steps_per_traced_ray": round(st["bvh_steps"] / max(1, st["rays"] - st["shadow_rays"]), 2)}

@@ -224,11 +224,13 @@ __global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t sha
 
 uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
 
-// auto: two passes in flight for BVH scenes (measured on the 1M-rectangle field: +50 % at 8 spp per pass); the fused
-// kernels of small scenes have no long tail to hide and gain nothing from a second pass (16.1 vs 15.9 Grays/s)
+// auto: two passes in flight.  BVH scenes: a launch ends with a few rays that walk hundreds of nodes on an otherwise
+// idle GPU and the other pass fills that tail (+50 % at 8 spp per pass on the 1M-rectangle field).  Small scenes: the
+// forward kernels are bound by arithmetic and latency, the backward sweep by HBM bandwidth, and one pass's sweep
+// runs under the other's forward kernels (+7.5 % on the sample scene, +5 % on the room; a third pass adds nothing).
 int pipes_wanted(const PtHandle *h) {
     const uint32_t c = h->cfg.concurrent_passes;
-    return c == 0 ? (h->sc.bvh_nodes ? 2 : 1) : (int)std::min<uint32_t>(c, PT_MAX_PIPES);
+    return c == 0 ? 2 : (int)std::min<uint32_t>(c, PT_MAX_PIPES);
 }
 
 int alloc_levels(PtHandle *h) {
@@ -248,7 +250,7 @@ int alloc_levels(PtHandle *h) {
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
     const uint64_t rec_bytes = Level::RECORD_BYTES;
-    const uint64_t budget = 48ull << 30;
+    const uint64_t budget = 80ull << 30;  // of the 288 GB of an MI355X
     for (;;) {
         uint64_t total = 0;
         for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4 * pipes_wanted(h);
