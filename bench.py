@@ -72,8 +72,10 @@ def main() -> None:
     ap.add_argument("--passes", type=int, default=-1,
                     help="pipeline passes in flight; 0 = library default (2); -1 = 1 for sample/room, so that the per-kernel "
                          "durations of the roofline block are not blurred by a second pass running concurrently (the "
-                         "library default is measured right after the timed region and reported as `pipelined`), "
-                         "library default for quads")
+                         "library default is measured by --pipelined), library default for quads")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="after the timed region, run the same steps again with the library's default of two passes in flight "
+                         "(no per-kernel events) and report that throughput as `pipelined`")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events (no roofline block)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,7 +134,7 @@ def main() -> None:
 
     st = gpu.stats()
     pipelined = None
-    if world == 1 and args.passes == 1 and not os.environ.get("PTGPU_FORCE_COLLECTIVE"):
+    if args.pipelined and world == 1:
         # the same steps with the library's default of two passes in flight (no per-kernel events)
         gpu.close()
         gpu = binding.PtGpu(device=local_rank, max_depth=args.max_depth, fuse_trace_shade=args.fused, samples_per_batch=args.batch,
