@@ -221,8 +221,13 @@ static int intersect_sphere(const pr_sphere *sphere, pr_vec3 p, pr_vec3 d, pr_hi
     return 0;
 }
 
+/* The four per-plane values scene.rs:244-253 recomputes for every ray: normalize(u), length(u), normalize(v),
+ * length(v).  The timing variant `hoist_plane_axes` evaluates them once per pass instead (same operations, same
+ * values, so the image does not change); the faithful path passes NULL and recomputes them as the reference does. */
+typedef struct { pr_vec3 u_hat, v_hat; float u_len, v_len; } pr_plane_axes;
+
 /* scene.rs:223-261 */
-static int intersect_plane(const pr_plane *plane, pr_vec3 p, pr_vec3 d, pr_hit *hit) {
+static int intersect_plane(const pr_plane *plane, const pr_plane_axes *ax, pr_vec3 p, pr_vec3 d, pr_hit *hit) {
     pr_vec3 n = plane->normal;
     pr_vec3 s = plane->origin;
     float num = n.x * (s.x - p.x) + n.y * (s.y - p.y) + n.z * (s.z - p.z);
@@ -232,10 +237,10 @@ static int intersect_plane(const pr_plane *plane, pr_vec3 p, pr_vec3 d, pr_hit *
     if (parameter < 0.0f) return 0;
     pr_vec3 position = vadd(p, vscale(d, parameter));
     pr_vec3 in_plane = vsub(position, s);
-    float on_u = vdot(in_plane, vnormalize(plane->u));
-    if (on_u > vlength(plane->u) || on_u < 0.0f) return 0;
-    float on_v = vdot(in_plane, vnormalize(plane->v));
-    if (on_v > vlength(plane->v) || on_v < 0.0f) return 0;
+    float on_u = vdot(in_plane, ax ? ax->u_hat : vnormalize(plane->u));
+    if (on_u > (ax ? ax->u_len : vlength(plane->u)) || on_u < 0.0f) return 0;
+    float on_v = vdot(in_plane, ax ? ax->v_hat : vnormalize(plane->v));
+    if (on_v > (ax ? ax->v_len : vlength(plane->v)) || on_v < 0.0f) return 0;
     hit->t = parameter; hit->position = position;
     if (vdot(d, n) < 0.0f) { hit->transition = 0; hit->normal = n; }
     else { hit->transition = 1; hit->normal = vneg(n); }
@@ -244,7 +249,8 @@ static int intersect_plane(const pr_plane *plane, pr_vec3 p, pr_vec3 d, pr_hit *
 
 /* scene.rs:263-297.  Iteration (and id) order: spheres, emissive_spheres, planes, emissive_planes;
  * a later hit replaces the nearest only when strictly closer; planes count only with Transition::In. */
-static int find_scene_hit(const pr_scene *scene, pr_vec3 p, pr_vec3 d, pr_hit *out, pr_stats *stats) {
+static int find_scene_hit(const pr_scene *scene, const pr_plane_axes *axes, pr_vec3 p, pr_vec3 d, pr_hit *out,
+                          pr_stats *stats) {
     int found = 0;
     pr_hit best, h;
     uint32_t id = 0;
@@ -265,7 +271,8 @@ static int find_scene_hit(const pr_scene *scene, pr_vec3 p, pr_vec3 d, pr_hit *o
         uint64_t n = list == 0 ? scene->n_planes : scene->n_emissive_planes;
         for (uint64_t i = 0; i < n; ++i, ++id) {
             if (stats) stats->prim_tests++;
-            if (intersect_plane(&arr[i], p, d, &h)) {
+            const pr_plane_axes *ax = axes ? &axes[(list == 0 ? 0 : scene->n_planes) + i] : NULL;
+            if (intersect_plane(&arr[i], ax, p, d, &h)) {
                 if (h.transition == 0) {
                     if (!found || h.t < best.t) { best = h; best.prim_id = id; found = 1; }
                 }
@@ -278,7 +285,7 @@ static int find_scene_hit(const pr_scene *scene, pr_vec3 p, pr_vec3 d, pr_hit *o
 }
 
 int32_t ptref_find_scene_hit(const pr_scene *scene, pr_vec3 origin, pr_vec3 direction, pr_hit *out) {
-    return find_scene_hit(scene, origin, direction, out, NULL);
+    return find_scene_hit(scene, NULL, origin, direction, out, NULL);
 }
 
 static const pr_material *prim_material(const pr_scene *sc, uint32_t id) {
@@ -301,6 +308,7 @@ typedef struct {
     uint32_t pixel, sample;
     pr_stats *stats;
     int math;
+    const pr_plane_axes *axes;  /* NULL: recompute per ray as the reference does */
 } pr_ctx;
 
 static inline uint32_t draw_u32(pr_ctx *c, uint32_t node, uint32_t dim) {
@@ -470,7 +478,7 @@ static pr_vec3 trace_radiance(pr_ctx *c, pr_vec3 origin, pr_vec3 direction, int 
         pr_vec3 light_ray = vsub(sample_point, origin);
         float light_distance = vlength(light_ray);
         pr_hit h;
-        if (find_scene_hit(scene, origin, vnormalize(light_ray), &h, c->stats)) {
+        if (find_scene_hit(scene, c->axes, origin, vnormalize(light_ray), &h, c->stats)) {
             if (h.t > light_distance - 0.000001f) return light_radiance;
             return zero;
         }
@@ -478,7 +486,7 @@ static pr_vec3 trace_radiance(pr_ctx *c, pr_vec3 origin, pr_vec3 direction, int 
     }
 
     pr_hit hit;
-    if (find_scene_hit(scene, origin, direction, &hit, c->stats)) {
+    if (find_scene_hit(scene, c->axes, origin, direction, &hit, c->stats)) {
         const float SHIFT_AMOUNT = 0.0001f;
         const float R = 0.04f;
         const pr_material *m = prim_material(scene, hit.prim_id);
@@ -543,7 +551,7 @@ static pr_vec3 trace_radiance(pr_ctx *c, pr_vec3 origin, pr_vec3 direction, int 
 pr_vec3 ptref_trace_radiance(const pr_scene *scene, const pr_options *opt, uint32_t *xorshift_state,
                              uint32_t pixel, uint32_t sample, pr_vec3 origin, pr_vec3 direction, int32_t depth,
                              pr_stats *stats) {
-    pr_ctx c = {scene, opt, xorshift_state, pixel, sample, stats, opt->math_mode};
+    pr_ctx c = {scene, opt, xorshift_state, pixel, sample, stats, opt->math_mode, NULL};
     return trace_radiance(&c, origin, direction, depth, 1u);
 }
 
@@ -600,10 +608,23 @@ static void primary_ray(pr_ctx *c, uint32_t x, uint32_t y, pr_vec3 *o, pr_vec3 *
     }
 }
 
-static void render_tile(const pr_scene *scene, const pr_options *opt, pr_backbuffer *bb, uint32_t *xs,
-                        uint32_t sample_index, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, pr_stats *stats) {
+static pr_plane_axes *hoisted_axes(const pr_scene *scene, const pr_options *opt) {
+    if (!opt->hoist_plane_axes) return NULL;
+    uint64_t n = scene->n_planes + scene->n_emissive_planes;
+    pr_plane_axes *ax = (pr_plane_axes *)malloc(sizeof(pr_plane_axes) * (size_t)(n ? n : 1));
+    for (uint64_t i = 0; i < n; ++i) {
+        const pr_plane *pl = i < scene->n_planes ? &scene->planes[i] : &scene->emissive_planes[i - scene->n_planes];
+        ax[i].u_hat = vnormalize(pl->u); ax[i].u_len = vlength(pl->u);
+        ax[i].v_hat = vnormalize(pl->v); ax[i].v_len = vlength(pl->v);
+    }
+    return ax;
+}
+
+static void render_tile(const pr_scene *scene, const pr_options *opt, const pr_plane_axes *axes, pr_backbuffer *bb,
+                        uint32_t *xs, uint32_t sample_index, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                        pr_stats *stats) {
     float iso_factor = scene->camera.iso / 100.0f;
-    pr_ctx c = {scene, opt, xs, 0, sample_index, stats, opt->math_mode};
+    pr_ctx c = {scene, opt, xs, 0, sample_index, stats, opt->math_mode, axes};
     for (uint32_t y = y0; y < y1; ++y) {
         for (uint32_t x = x0; x < x1; ++x) {
             uint32_t index = y * bb->width + x;
@@ -626,6 +647,7 @@ static void render_tile(const pr_scene *scene, const pr_options *opt, pr_backbuf
 void ptref_render_pass(const pr_scene *scene, const pr_options *opt, pr_backbuffer *bb, uint32_t *xorshift_state,
                        uint32_t sample_index, pr_stats *stats) {
     uint32_t ntx = (bb->width + TILE_SIZE - 1) / TILE_SIZE, nty = (bb->height + TILE_SIZE - 1) / TILE_SIZE;
+    pr_plane_axes *axes = hoisted_axes(scene, opt);
     for (uint32_t ty = 0; ty < nty; ++ty)
         for (uint32_t tx = 0; tx < ntx; ++tx) {
             uint32_t x0 = tx * TILE_SIZE, y0 = ty * TILE_SIZE;
@@ -633,13 +655,14 @@ void ptref_render_pass(const pr_scene *scene, const pr_options *opt, pr_backbuff
             /* the reference never clips (window.rs:174-175) and panics past the image; clipped here */
             if (x1 > bb->width) x1 = bb->width;
             if (y1 > bb->height) y1 = bb->height;
-            render_tile(scene, opt, bb, xorshift_state, sample_index, x0, y0, x1, y1, stats);
+            render_tile(scene, opt, axes, bb, xorshift_state, sample_index, x0, y0, x1, y1, stats);
         }
+    free(axes);
 }
 
 void ptref_primary_ids(const pr_scene *scene, const pr_options *opt, uint32_t sample_index, uint32_t *ids) {
     uint32_t xs = opt->seed ? opt->seed : 314159265u;
-    pr_ctx c = {scene, opt, &xs, 0, sample_index, NULL, opt->math_mode};
+    pr_ctx c = {scene, opt, &xs, 0, sample_index, NULL, opt->math_mode, NULL};
     for (uint32_t y = 0; y < scene->height; ++y)
         for (uint32_t x = 0; x < scene->width; ++x) {
             uint32_t index = y * scene->width + x;
@@ -647,7 +670,7 @@ void ptref_primary_ids(const pr_scene *scene, const pr_options *opt, uint32_t sa
             pr_vec3 o, d;
             primary_ray(&c, x, y, &o, &d);
             pr_hit h;
-            find_scene_hit(scene, o, d, &h, NULL);
+            find_scene_hit(scene, NULL, o, d, &h, NULL);
             ids[index] = h.prim_id;
         }
 }
@@ -658,6 +681,7 @@ void ptref_primary_ids(const pr_scene *scene, const pr_options *opt, uint32_t sa
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     const pr_scene *scene; const pr_options *opt; pr_backbuffer *bb;
+    const pr_plane_axes *axes;
     uint32_t sample_index;
     pthread_mutex_t mu;
     uint32_t next_tile, n_tiles, ntx;
@@ -678,7 +702,7 @@ static void *pool_main(void *arg) {
         uint32_t x0 = tx * TILE_SIZE, y0 = ty * TILE_SIZE, x1 = x0 + TILE_SIZE, y1 = y0 + TILE_SIZE;
         if (x1 > sh->bb->width) x1 = sh->bb->width;
         if (y1 > sh->bb->height) y1 = sh->bb->height;
-        render_tile(sh->scene, sh->opt, sh->bb, &t->xs, sh->sample_index, x0, y0, x1, y1, &t->stats);
+        render_tile(sh->scene, sh->opt, sh->axes, sh->bb, &t->xs, sh->sample_index, x0, y0, x1, y1, &t->stats);
     }
     return NULL;
 }
@@ -688,6 +712,8 @@ void ptref_render_pass_pool(const pr_scene *scene, const pr_options *opt, pr_bac
     if (n_threads < 1) n_threads = 1;
     pool_shared sh;
     sh.scene = scene; sh.opt = opt; sh.bb = bb; sh.sample_index = sample_index;
+    pr_plane_axes *axes = hoisted_axes(scene, opt);
+    sh.axes = axes;
     sh.ntx = (bb->width + TILE_SIZE - 1) / TILE_SIZE;
     sh.n_tiles = sh.ntx * ((bb->height + TILE_SIZE - 1) / TILE_SIZE);
     sh.next_tile = 0;
@@ -706,5 +732,5 @@ void ptref_render_pass_pool(const pr_scene *scene, const pr_options *opt, pr_bac
         if (stats) { stats->rays += pt[i].stats.rays; stats->prim_tests += pt[i].stats.prim_tests; }
     }
     pthread_mutex_destroy(&sh.mu);
-    free(th); free(pt);
+    free(th); free(pt); free(axes);
 }

@@ -91,6 +91,8 @@ typedef struct {
     int32_t camera_model;     /* 0: pinhole_ray (what render() calls, tracer.rs:629); 1: thin_lens_ray (tracer.rs:144-197) */
     float focus_distance;     /* thin lens; reference constant 10.0 (tracer.rs:155) */
     float lens_aperture;      /* thin lens; reference constant 4.0 (tracer.rs:177) */
+    int32_t hoist_plane_axes; /* timing variant only: 1 = normalize(u), length(u), normalize(v), length(v) of every plane
+                                 once per pass instead of once per ray and plane (scene.rs:244-253); same image */
 } pr_options;
 
 typedef struct {

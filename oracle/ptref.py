@@ -50,7 +50,7 @@ class Scene(C.Structure):
 class Options(C.Structure):
     _fields_ = [("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("seed", C.c_uint32), ("max_depth", C.c_int32),
                 ("sub_pixel_override", C.c_int32), ("camera_model", C.c_int32), ("focus_distance", C.c_float),
-                ("lens_aperture", C.c_float)]
+                ("lens_aperture", C.c_float), ("hoist_plane_axes", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -137,8 +137,9 @@ def camera_new(cam) -> Camera:
 
 
 def options(rng_mode=RNG_COUNTER, math_mode=MATH_DET, seed=314159265, max_depth=4, sub_pixel_override=-1, camera_model=0,
-            focus_distance=10.0, lens_aperture=4.0) -> Options:
-    return Options(rng_mode, math_mode, seed, max_depth, sub_pixel_override, camera_model, focus_distance, lens_aperture)
+            focus_distance=10.0, lens_aperture=4.0, hoist_plane_axes=0) -> Options:
+    return Options(rng_mode, math_mode, seed, max_depth, sub_pixel_override, camera_model, focus_distance, lens_aperture,
+                   hoist_plane_axes)
 
 
 class OracleScene:

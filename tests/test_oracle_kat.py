@@ -199,3 +199,15 @@ def test_thin_lens_draws_follow_the_pinhole_draws(oracle):
     b = osc.primary_ids(oracle.options(camera_model=1), 0)
     c = osc.primary_ids(oracle.options(camera_model=1), 0)
     assert np.array_equal(b, c) and not np.array_equal(a, b)
+
+
+def test_hoisted_plane_axes_is_a_timing_variant_only(oracle):
+    """The CPU baseline's second figure evaluates normalize(u), length(u), normalize(v), length(v) of each plane once per
+    pass instead of per ray and plane (scene.rs:244-253): the same operations on the same inputs, so every accumulator
+    and the ray count must come out identical, serial and through the worker pool."""
+    R = oracle
+    sc = R.OracleScene(S.sample_scene(48, 40, camera_width=6.0))
+    for rng, math, threads in ((R.RNG_XORSHIFT, R.MATH_LIBM, 0), (R.RNG_COUNTER, R.MATH_DET, 3)):
+        a = sc.render(R.options(rng, math), 3, threads=threads)
+        b = sc.render(R.options(rng, math, hoist_plane_axes=1), 3, threads=threads)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
