@@ -58,8 +58,8 @@ def test_deterministic_math_vs_libm_same_rng(binding, oracle):
 
 
 def test_full_size_1080p_properties(binding, oracle):
-    """At the benchmark's size (1920x1080) the oracle is too slow for a pixel-for-pixel render, so check what does
-    not depend on size: sharded + combined == unsharded (linearity of the integer accumulator), incremental ==
+    """At the benchmark's size (1920x1080) the oracle affords only a few samples per pixel (the test after this one), so
+    also check what does not depend on size: sharded + combined == unsharded (linearity of the integer accumulator), incremental ==
     one-shot, pixels8 is the documented function of pixels32, accumulator bounds, ray bookkeeping."""
     sc = S.sample_scene(1920, 1080, camera_width=8.8888889)
     with binding.PtGpu() as gpu:
@@ -97,3 +97,19 @@ def test_full_size_1080p_properties(binding, oracle):
         for dx in (0, 1, 2):
             inner[1:-1, 1:-1] &= ids[dy:ids.shape[0] - 2 + dy, dx:ids.shape[1] - 2 + dx] == 9
     assert inner.sum() > 1000 and np.all(full[inner] == 6 * 255)
+
+
+@pytest.mark.parametrize("width,height,spp", [(1920, 1080, 4), (3840, 2160, 1)])
+def test_full_size_pixels_bit_exact(binding, oracle, width, height, spp):
+    """The benchmark's own image sizes, pixel for pixel: the oracle's worker pool (counter RNG, deterministic math: the
+    result does not depend on which thread renders which tile) finishes a few samples per pixel in seconds."""
+    sc = S.sample_scene(width, height, camera_width=8.8888889)
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(spp)
+        p32, n = gpu.read_pixels32()
+        p8 = gpu.read_pixels8()
+        st = gpu.stats()
+    r32, r8, rays = oracle.OracleScene(sc).render(oracle.options(oracle.RNG_COUNTER, oracle.MATH_DET), spp, threads=16)
+    assert n == spp and st["rays"] == rays
+    assert np.array_equal(p32, r32) and np.array_equal(p8, r8)
