@@ -171,14 +171,20 @@ float4 mat3(const PtMaterial &m) {
 }
 
 // Per-plane constants of intersect_plane (reference src/scene.rs:244-249), computed once with the same operations.
+// An axis-aligned rectangle (see plane_test_axis) is stored with its edges in the order the short test expects.
 void pack_plane(const PtPlane &p, float4 *out) {
     V3 u = toV3(p.u), v = toV3(p.v);
     V3 un = normalize(u), vn = normalize(v);
     float ul = length(u), vl = length(v);
+    bool swap_edges;
+    uint32_t code = plane_axis_code(toV3(p.normal), toV3(p.origin), un, ul, vn, vl, swap_edges);
+    if (swap_edges) { std::swap(un, vn); std::swap(ul, vl); }
+    float code_bits;
+    memcpy(&code_bits, &code, 4);
     out[0] = make_float4(p.normal.x, p.normal.y, p.normal.z, p.origin.x);
     out[1] = make_float4(p.origin.y, p.origin.z, un.x, un.y);
     out[2] = make_float4(un.z, ul, vn.x, vn.y);
-    out[3] = make_float4(vn.z, vl, 0.0f, 0.0f);
+    out[3] = make_float4(vn.z, vl, code_bits, 0.0f);
 }
 
 hipEvent_t get_event(PtHandle *h) {

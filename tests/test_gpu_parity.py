@@ -360,3 +360,44 @@ def test_more_passes_than_flag_slots_between_synchronisations(binding, oracle):
         st = gpu.stats()
     r32, _, rays = oracle.OracleScene(sc).render(oracle.options(max_depth=5), 1100, threads=8)
     assert n == 1100 and np.array_equal(p32, r32) and st["rays"] == rays
+
+
+# ---- axis-aligned rectangles take a shorter plane test on the device ------------------------------------------------
+def _axis_box_scene(width=96, height=72):
+    """Six inward walls whose normals run along +-x, +-y, +-z, with the edge that runs along the 'next' axis given first
+    on some walls and second on others and with negative edge directions; one tilted rectangle (general test) between
+    them; a wall lying exactly in the camera's projection plane, so that the numerator of its plane equation is a sum
+    of zeros for every primary ray; a glass sphere (total internal reflection makes NaN rays, which must take the
+    general test) and a light."""
+    grey = S.Material.physically((0.8, 0.8, 0.8), 0.9, 0.0)
+    red = S.Material.physically((0.9, 0.2, 0.2), 0.5, 0.0)
+    gold = S.Material.physically((1.0, 0.8, 0.4), 0.2, 1.0)
+    sc = S.Scene(
+        image_settings=S.ImageSettings(width, height, True),
+        camera=S.Camera((0.0, 5.0, 15.0), (0.0, 5.0, 0.0), (0.0, 1.0, 0.0), 8.0, 6.0, 10.0, S.TONE_CLAMP, 1.0, 200.0),
+        sky=S.Sky.constant((0.2, 0.2, 0.2)),
+    )
+    sc.add(S.Plane((5.0, 0.0, 5.0), (0.0, 0.0, -10.0), (-10.0, 0.0, 0.0), grey))     # floor, n = +y, negative edges
+    sc.add(S.Plane((-5.0, 10.0, -5.0), (10.0, 0.0, 0.0), (0.0, 0.0, 10.0), grey))    # ceiling, n = -y, edges the other way round
+    sc.add(S.Plane((-5.0, 0.0, -5.0), (10.0, 0.0, 0.0), (0.0, 10.0, 0.0), gold))     # back wall, n = +z
+    sc.add(S.Plane((-5.0, 0.0, -5.0), (0.0, 10.0, 0.0), (0.0, 0.0, 10.0), red))      # left wall, n = +x
+    sc.add(S.Plane((5.0, 0.0, -5.0), (0.0, 0.0, 10.0), (0.0, 10.0, 0.0), grey))      # right wall, n = -x, edges the other way round
+    sc.add(S.Plane((2.0, 1.0, 5.0), (2.0, 0.0, 0.0), (0.0, 2.0, 0.0), gold))         # in the projection plane z = 5, n = +z
+    sc.add(S.Plane((5.0, 0.0, 16.0), (-10.0, 0.0, 0.0), (0.0, 10.0, 0.0), grey))     # behind the camera, n = -z
+    sc.add(S.Plane((-1.0, 0.5, 1.0), (3.0, 0.5, 0.0), (0.0, 0.4, -3.0), red))        # tilted: general test
+    sc.add(S.Plane((-2.0, 9.9, -2.0), (4.0, 0.0, 0.0), (0.0, 0.0, 4.0), S.Material.emissive((12.0, 12.0, 12.0))))
+    sc.add(S.Sphere((2.0, 2.0, 0.0), 2.0, S.Material.translucent(1.5)))
+    sc.add(S.Sphere((-2.5, 1.5, 2.0), 1.5, gold))
+    return sc
+
+
+def test_axis_aligned_rectangles_short_test(binding, oracle):
+    sc = _axis_box_scene()
+    p32, p8, ns, st = _gpu_render(binding, sc, 5, max_depth=5)
+    osc, opt, (r32, r8, rays) = _oracle_render(oracle, sc, 5, max_depth=5)
+    assert np.array_equal(p32, r32) and np.array_equal(p8, r8) and st["rays"] == rays
+    for jitter in (0, 1):
+        with binding.PtGpu(sub_pixel_override=jitter) as gpu:
+            gpu.upload_scene(sc)
+            ids = gpu.primary_ids(1)
+        assert np.array_equal(ids, osc.primary_ids(oracle.options(sub_pixel_override=jitter), 1))
