@@ -130,7 +130,10 @@ def main() -> None:
     for _ in range(args.steps):
         gpu.render(args.spp_per_step)
     gpu.sync()
+    t_exchange = time.perf_counter()
     total_spp = D.combine_accumulators(gpu, args.steps * args.spp_per_step)
+    torch.cuda.synchronize(dev)
+    t_exchange = time.perf_counter() - t_exchange   # export + RCCL all-reduce + import, inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -215,6 +218,10 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": round(alg / n_launch, 1),
                 "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
             }
+        if dist.is_initialized():
+            # the one exchange step of the job (this rank's wall time for it: waiting for the slowest rank included)
+            out["exchange"] = {"op": "all_reduce(SUM) of the u32 accumulator, once per timed region",
+                               "bytes": args.width * args.height * 12, "ms": round(1e3 * t_exchange, 3)}
         if pipelined is not None:
             out["pipelined"] = pipelined
         out["config"]["passes_in_flight"] = args.passes if args.passes else 2

@@ -28,3 +28,4 @@ def test_bench_under_torchrun_with_nccl_collective():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["config"]["accumulated_spp"] == 2 * d["config"]["spp_per_step"] and d["value"] > 0
     assert d["roofline"]["kernel"] == "trace_shade" and 0 < d["roofline"]["frac"] < 1
+    assert d["exchange"]["bytes"] == 640 * 360 * 12 and d["exchange"]["ms"] > 0
