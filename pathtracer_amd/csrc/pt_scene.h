@@ -167,15 +167,17 @@ PT_HD bool plane_test_axis(T4 q0, T4 q1, T4 q2, T4 q3, V3 p, V3 d, float &t) {
 #endif
         if (num == 0.0f) num = n.x * (s.x - p.x) + n.y * (s.y - p.y) + n.z * (s.z - p.z);
     }
-    if (__builtin_fabsf(denum) < 0.0000001f) return false;
+    // From here on no lane leaves early: a wave runs every instruction below for as long as one of its lanes needs
+    // it, so returning early saves nothing, while each nested exit costs scalar instructions for the EXEC mask.
+    bool ok = !(__builtin_fabsf(denum) < 0.0000001f);
     float parameter = num / denum;
-    if (parameter < 0.0f) return false;
+    ok &= !(parameter < 0.0f);
     float on1 = ((axis_of<A1>(p) + parameter * axis_of<A1>(d)) - axis_of<A1>(s)) * axis_of<A1>(un);
-    if (on1 > q2.y || on1 < 0.0f) return false;
+    ok &= !(on1 > q2.y) & !(on1 < 0.0f);
     float on2 = ((axis_of<A2>(p) + parameter * axis_of<A2>(d)) - axis_of<A2>(s)) * axis_of<A2>(vn);
-    if (on2 > q3.y || on2 < 0.0f) return false;
+    ok &= !(on2 > q3.y) & !(on2 < 0.0f);
     t = parameter;
-    return true;
+    return ok;
 }
 
 // Host side of the above: 0 when the plane does not qualify, else 1 + the normal's axis A; `swap_edges` tells the
@@ -232,9 +234,11 @@ PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p
         else if (code == 2u) hit = plane_test_axis<1>(q0, q1, q2, q3, p, d, t);
         else if (code == 3u) hit = plane_test_axis<2>(q0, q1, q2, q3, p, d, t);
         else hit = plane_test(q0, q1, q2, q3, p, d, t, pos);
-        if (hit) {
-            if (best == MISS || t < best_t) { best = n_sph + i; best_t = t; best_out = 0; }
-        }
+        // (selects instead of a nested branch: the same three writes without two EXEC-mask round trips)
+        const bool take = hit && (best == MISS || t < best_t);
+        best = take ? n_sph + i : best;
+        best_t = take ? t : best_t;
+        best_out = take ? 0 : best_out;
     }
     return best;
 }
