@@ -52,8 +52,8 @@ constexpr uint32_t BVH_TRAV_BLOCKS = 2048;  // most blocks a traversing kernel i
 #if defined(__HIPCC__)
 // Slab test of two children at once (called twice per node).  Distances are lo * inv + (-o * inv) in one fused
 // operation per plane pair (v_pk_fma_f32); against (lo - o) * inv that moves a slab by at most ~|o| * 2^-23, far
-// inside the builder's padding.  NaN distances (inf - inf when the ray is parallel to a slab, 0 * inf) drop out of
-// fminf/fmaxf, which only removes a constraint; tfar is widened by 4 ulp for the rounding of the products.
+// inside the builder's padding.  inv is finite (slab_reciprocal); a NaN distance (0 * inf cannot occur any more, but a
+// NaN ray can) drops out of fminf/fmaxf; tfar is widened by 4 ulp for the rounding of the products.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 min2(f32x2 x, f32x2 y) { return f32x2{fminf(x.x, y.x), fminf(x.y, y.y)}; }
 __device__ __forceinline__ f32x2 max2(f32x2 x, f32x2 y) { return f32x2{fmaxf(x.x, y.x), fmaxf(x.y, y.y)}; }
@@ -66,6 +66,19 @@ __device__ __forceinline__ void box_entry2(f32x2 lox, f32x2 loy, f32x2 loz, f32x
     f32x2 t0z = __builtin_elementwise_fma(loz, iz, nz), t1z = __builtin_elementwise_fma(hiz, iz, nz);
     tn = max2(max2(min2(t0x, t1x), min2(t0y, t1y)), max2(min2(t0z, t1z), f32x2{0.0f, 0.0f}));
     tf = min2(min2(max2(t0x, t1x), max2(t0y, t1y)), max2(t0z, t1z)) * 1.0000005f;
+}
+
+// 1/d for the slab test, with its magnitude capped at 2^64.  An infinite reciprocal (a direction component that is
+// zero, as in the centre column of an un-jittered image, or denormal) would make lo * inv - o * inv the difference of
+// two infinities whenever lo and o have the same sign; the NaN would drop out of fminf/fmaxf and leave the slab's
+// other end (an infinity of the wrong sign) as both its entry and its exit: the box, and everything in it, culled.
+// With a finite power of two the products are exact, lo * inv + noi has the sign of lo - o, a ray inside the slab
+// gets (-huge, +huge) and a ray beside it is culled or not according to that sign.  Capping only ever shortens a
+// distance without changing its sign, which can keep a box that could have been culled, never the reverse (for
+// coordinates below 2^63; the cap also covers a NaN direction, whose primitive tests all fail anyway).
+__device__ __forceinline__ float slab_reciprocal(float d) {
+    float r = 1.0f / d;
+    return __builtin_fabsf(r) <= 0x1p64f ? r : __builtin_copysignf(0x1p64f, d);
 }
 
 // A candidate replaces the current nearest when (t, id) is lexicographically smaller.
@@ -155,7 +168,7 @@ __device__ __forceinline__ void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &
     s.best_t = __builtin_inff();
     s.best_out = 0;
     bvh_test_prims(sc, sc.bvh_always, sc.n_always, o, d, s.best, s.best_t, s.best_out);
-    s.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    s.inv = v3(slab_reciprocal(d.x), slab_reciprocal(d.y), slab_reciprocal(d.z));
     s.noi = v3(-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z));
     s.node = 0;
     s.sp = 0;

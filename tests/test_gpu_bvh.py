@@ -124,3 +124,20 @@ def test_concurrent_passes_sum_to_the_same_image(binding, oracle, pipes):
     r32, _, r_rays = osc.render(oracle.options(), 9)
     assert np.array_equal(p32, r32) and rays == r_rays
     assert np.array_equal(q32, osc.render(oracle.options(), 3)[0])
+
+
+def test_rays_parallel_to_an_axis(binding, oracle):
+    """Without jitter the centre column and row of a symmetric camera have a direction component that is exactly zero:
+    the slab test must not turn the infinite reciprocal into a culled box."""
+    sc = S.sample_scene(64, 64)
+    osc = oracle.OracleScene(sc)
+    ref = osc.primary_ids(oracle.options(sub_pixel_override=0), 0)
+    assert (ref[:, 32] != 0xFFFFFFFF).all()
+    with binding.PtGpu(accel=2, sub_pixel_override=0) as gpu:
+        gpu.upload_scene(sc)
+        ids = gpu.primary_ids(0)
+        gpu.render(2)
+        p32, _ = gpu.read_pixels32()
+    assert np.array_equal(ids, ref)
+    r32, _, _ = osc.render(oracle.options(sub_pixel_override=0), 2)
+    assert np.array_equal(p32, r32)

@@ -1,0 +1,107 @@
+"""Randomised parity: small random scenes, every one rendered by the linear-scan kernels, by the BVH kernels and by the
+oracle; all three must agree bit for bit (ids, accumulators, display bytes, ray counts).
+
+The generator leans on the cases the device code treats specially: axis-aligned rectangles in every orientation, edge
+order and edge sign (the short plane test), rectangles through the camera's projection plane and through other
+primitives' surfaces (zero numerators, equal distances), tilted rectangles, glass inside glass, lights of both kinds,
+all three tone maps, jitter on and off, depths 1..6 and the thin-lens camera.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _material(rng):
+    k = rng.randint(0, 10)
+    if k == 0:
+        return S.Material.mirror()
+    if k == 1:
+        return S.Material.none()
+    if k <= 3:
+        return S.Material.translucent(float(rng.choice([1.1, 1.33, 1.5, 2.4])))
+    if k == 4:
+        return S.Material.emissive(tuple(float(x) for x in rng.uniform(0.5, 12.0, 3)))
+    return S.Material.physically(tuple(float(x) for x in rng.uniform(0.05, 1.0, 3)), float(rng.choice([0.0, 0.2, 0.5, 0.8, 1.0])),
+                                 float(rng.choice([0.0, 0.0, 1.0, 0.5])))
+
+
+def _axis_rectangle(rng, lo, hi):
+    """A rectangle normal to a random axis at a grid coordinate, edges along the two other axes in random order and
+    direction (grid coordinates make coplanar and touching rectangles likely)."""
+    a = rng.randint(0, 3)
+    b, c = [(1, 2), (2, 0), (0, 1)][a] if rng.rand() < 0.5 else [(2, 1), (0, 2), (1, 0)][a]
+    origin = np.array([float(rng.randint(lo, hi + 1)) for _ in range(3)])
+    u = np.zeros(3)
+    v = np.zeros(3)
+    u[b] = float(rng.randint(1, hi - lo + 1)) * (1.0 if rng.rand() < 0.5 else -1.0)
+    v[c] = float(rng.randint(1, hi - lo + 1)) * (1.0 if rng.rand() < 0.5 else -1.0)
+    return tuple(origin), tuple(u), tuple(v)
+
+
+def random_scene(seed, width=40, height=30):
+    rng = np.random.RandomState(1000 + seed)
+    tone = int(rng.choice([S.TONE_CLAMP, S.TONE_REINHARD, S.TONE_EXPOSURE]))
+    z_near = float(rng.choice([2.0, 5.0, 10.0]))
+    cam_z = float(rng.choice([10.0, 12.0, 15.0]))
+    sc = S.Scene(
+        image_settings=S.ImageSettings(width, height, bool(rng.rand() < 0.7)),
+        camera=S.Camera((float(rng.randint(-2, 3)), float(rng.randint(2, 7)), cam_z), (0.0, float(rng.randint(2, 6)), 0.0), (0.0, 1.0, 0.0),
+                        8.0, 6.0, z_near, tone, float(rng.uniform(0.3, 2.0)), float(rng.choice([100.0, 200.0, 400.0]))),
+        sky=S.Sky.constant(tuple(float(x) for x in rng.uniform(0.0, 1.0, 3))),
+    )
+    grey = S.Material.physically((0.8, 0.8, 0.8), float(rng.choice([0.3, 0.9])), 0.0)
+    if rng.rand() < 0.5:   # floor and back wall, edges in either order
+        sc.add(S.Plane((-8.0, 0.0, 8.0), (16.0, 0.0, 0.0), (0.0, 0.0, -16.0), grey))
+        sc.add(S.Plane((-8.0, 0.0, -6.0), (16.0, 0.0, 0.0), (0.0, 12.0, 0.0), _material(rng)))
+    else:
+        sc.add(S.Plane((-8.0, 0.0, -8.0), (0.0, 0.0, 16.0), (16.0, 0.0, 0.0), grey))
+        sc.add(S.Plane((8.0, 12.0, -6.0), (-16.0, 0.0, 0.0), (0.0, -12.0, 0.0), _material(rng)))
+    if rng.rand() < 0.5:   # close the box, so that paths live to the depth limit
+        sc.add(S.Plane((-8.0, 12.0, -6.0), (16.0, 0.0, 0.0), (0.0, 0.0, 22.0), _material(rng)))   # ceiling, faces down
+        sc.add(S.Plane((-8.0, 0.0, -6.0), (0.0, 12.0, 0.0), (0.0, 0.0, 22.0), _material(rng)))    # left, faces +x
+        sc.add(S.Plane((8.0, 0.0, 16.0), (0.0, 12.0, 0.0), (0.0, 0.0, -22.0), _material(rng)))    # right, faces -x
+        sc.add(S.Plane((8.0, 0.0, 16.0), (-16.0, 0.0, 0.0), (0.0, 12.0, 0.0), grey))              # behind the camera, faces -z
+    if rng.rand() < 0.6:   # a light overhead, facing down
+        sc.add(S.Plane((-2.0, 9.5, -2.0), (4.0, 0.0, 0.0), (0.0, 0.0, 4.0), S.Material.emissive((10.0, 9.0, 8.0))))
+    for _ in range(rng.randint(0, 7)):
+        sc.add(S.Sphere(tuple(float(x) for x in rng.uniform(-4.0, 4.0, 3) + np.array([0.0, 4.0, 0.0])), float(rng.uniform(0.4, 2.5)), _material(rng)))
+    for _ in range(rng.randint(1, 10)):
+        if rng.rand() < 0.7:
+            o, u, v = _axis_rectangle(rng, -5, 5)
+            o = (o[0], o[1] + 5.0, o[2])
+        else:
+            o = tuple(float(x) for x in rng.uniform(-5.0, 5.0, 3) + np.array([0.0, 5.0, 0.0]))
+            u = tuple(float(x) for x in rng.uniform(-6.0, 6.0, 3))
+            w = rng.uniform(-6.0, 6.0, 3)
+            v = tuple(float(x) for x in np.cross(np.array(u), w) / 6.0)   # perpendicular to u
+        sc.add(S.Plane(o, u, v, _material(rng)))
+    if rng.rand() < 0.5:   # a rectangle in the projection plane: every primary ray starts on it
+        zc = cam_z - z_near
+        sc.add(S.Plane((float(rng.randint(-4, 1)), float(rng.randint(1, 4)), zc), (float(rng.randint(1, 5)), 0.0, 0.0), (0.0, float(rng.randint(1, 4)), 0.0),
+                       _material(rng)))
+    return sc, int(rng.randint(1, 7)), int(rng.randint(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_scene_three_ways(binding, oracle, seed):
+    sc, depth, thin = random_scene(seed)
+    spp = 3
+    osc = oracle.OracleScene(sc)
+    opt = oracle.options(oracle.RNG_COUNTER, oracle.MATH_DET, max_depth=depth, camera_model=thin)
+    r32, r8, rays = osc.render(opt, spp)
+    ids = osc.primary_ids(opt, 1)
+    for accel in (1, 2):   # linear scan, BVH
+        with binding.PtGpu(accel=accel, max_depth=depth, camera_model=thin) as gpu:
+            gpu.upload_scene(sc)
+            gpu.render(spp)
+            p32, n = gpu.read_pixels32()
+            p8 = gpu.read_pixels8()
+            st = gpu.stats()
+            got_ids = gpu.primary_ids(1)
+        assert n == spp
+        assert np.array_equal(got_ids, ids), (seed, accel)
+        assert st["rays"] == rays, (seed, accel)
+        assert np.array_equal(p32, r32) and np.array_equal(p8, r8), (seed, accel)
