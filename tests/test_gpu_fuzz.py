@@ -4,7 +4,8 @@ oracle; all three must agree bit for bit (ids, accumulators, display bytes, ray 
 The generator leans on the cases the device code treats specially: axis-aligned rectangles in every orientation, edge
 order and edge sign (the short plane test), rectangles through the camera's projection plane and through other
 primitives' surfaces (zero numerators, equal distances), tilted rectangles, glass inside glass, lights of both kinds,
-all three tone maps, jitter on and off, depths 1..6 and the thin-lens camera.
+all three tone maps, constant and textured sky, jitter on and off, depths 1..6, the thin-lens camera, a sphere around the
+camera, degenerate primitives; the linear scan runs in each of its pipeline variants in turn.
 """
 import numpy as np
 import pytest
@@ -41,7 +42,7 @@ def _axis_rectangle(rng, lo, hi):
     return tuple(origin), tuple(u), tuple(v)
 
 
-def random_scene(seed, width=40, height=30):
+def random_scene(seed, width=48, height=36):
     rng = np.random.RandomState(1000 + seed)
     tone = int(rng.choice([S.TONE_CLAMP, S.TONE_REINHARD, S.TONE_EXPOSURE]))
     z_near = float(rng.choice([2.0, 5.0, 10.0]))
@@ -82,10 +83,18 @@ def random_scene(seed, width=40, height=30):
         zc = cam_z - z_near
         sc.add(S.Plane((float(rng.randint(-4, 1)), float(rng.randint(1, 4)), zc), (float(rng.randint(1, 5)), 0.0, 0.0), (0.0, float(rng.randint(1, 4)), 0.0),
                        _material(rng)))
+    if rng.rand() < 0.15:  # the camera sits inside this one: primary rays leave it (Transition::Out)
+        sc.add(S.Sphere((0.0, 5.0, cam_z - 1.0), float(rng.uniform(12.0, 30.0)), _material(rng)))
+    if rng.rand() < 0.1:   # degenerate primitives: a point sphere, a rectangle without area (its normal is NaN)
+        sc.add(S.Sphere((1.0, 3.0, 0.0), 0.0, _material(rng)))
+        sc.add(S.Plane((0.0, 4.0, 0.0), (0.0, 0.0, 0.0), (0.0, 2.0, 0.0), _material(rng)))
+    if rng.rand() < 0.25:
+        tex = rng.uniform(0.0, 4.0, (8, 16, 3)).astype(np.float32)
+        sc.sky = S.Sky.hdri("random.hdr", tex)
     return sc, int(rng.randint(1, 7)), int(rng.randint(0, 2))
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(384))
 def test_random_scene_three_ways(binding, oracle, seed):
     sc, depth, thin = random_scene(seed)
     spp = 3
@@ -93,8 +102,10 @@ def test_random_scene_three_ways(binding, oracle, seed):
     opt = oracle.options(oracle.RNG_COUNTER, oracle.MATH_DET, max_depth=depth, camera_model=thin)
     r32, r8, rays = osc.render(opt, spp)
     ids = osc.primary_ids(opt, 1)
-    for accel in (1, 2):   # linear scan, BVH
-        with binding.PtGpu(accel=accel, max_depth=depth, camera_model=thin) as gpu:
+    # linear scan in one of its four pipeline variants, then the BVH; one or two passes in flight, several passes per call
+    for accel, cfg in ((1, dict(fuse_trace_shade=seed % 4, concurrent_passes=1 + seed % 2, samples_per_batch=1 + seed % 3)),
+                       (2, dict(concurrent_passes=1 + (seed // 2) % 2, samples_per_batch=1 + (seed // 3) % 3))):
+        with binding.PtGpu(accel=accel, max_depth=depth, camera_model=thin, **cfg) as gpu:
             gpu.upload_scene(sc)
             gpu.render(spp)
             p32, n = gpu.read_pixels32()
