@@ -83,6 +83,13 @@ def random_scene(seed, width=48, height=36):
         zc = cam_z - z_near
         sc.add(S.Plane((float(rng.randint(-4, 1)), float(rng.randint(1, 4)), zc), (float(rng.randint(1, 5)), 0.0, 0.0), (0.0, float(rng.randint(1, 4)), 0.0),
                        _material(rng)))
+    for _ in range(rng.randint(0, 3)):   # exact copies under another material: equal distances, the earlier id must win
+        if rng.rand() < 0.5 and sc.spheres:
+            src = sc.spheres[rng.randint(0, len(sc.spheres))]
+            sc.add(S.Sphere(src.origin, src.radius, _material(rng)))
+        elif sc.planes:
+            src = sc.planes[rng.randint(0, len(sc.planes))]
+            sc.add(S.Plane(src.origin, src.u, src.v, _material(rng)))
     if rng.rand() < 0.15:  # the camera sits inside this one: primary rays leave it (Transition::Out)
         sc.add(S.Sphere((0.0, 5.0, cam_z - 1.0), float(rng.uniform(12.0, 30.0)), _material(rng)))
     if rng.rand() < 0.1:   # degenerate primitives: a point sphere, a rectangle without area (its normal is NaN)
@@ -116,3 +123,49 @@ def test_random_scene_three_ways(binding, oracle, seed):
         assert np.array_equal(got_ids, ids), (seed, accel)
         assert st["rays"] == rays, (seed, accel)
         assert np.array_equal(p32, r32) and np.array_equal(p8, r8), (seed, accel)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soup_bvh_equals_linear_scan(binding, oracle, seed):
+    """A few thousand small primitives on a coarse grid (many coplanar, touching and duplicated ones, so equal distances
+    are common): the BVH must pick the primitive the linear scan picks, for primary ids against the oracle and for the
+    accumulated image against the GPU's own linear scan."""
+    rng = np.random.RandomState(77 + seed)
+    sc = S.Scene(
+        image_settings=S.ImageSettings(96, 72, bool(seed % 2)),
+        camera=S.Camera((0.0, 6.0, 22.0), (0.0, 5.0, 0.0), (0.0, 1.0, 0.0), 8.0, 6.0, 6.0, S.TONE_REINHARD, 1.0, 100.0),
+        sky=S.Sky.constant((0.6, 0.7, 0.9)),
+    )
+    n = 1500 + 500 * seed
+    for i in range(n):
+        k = rng.rand()
+        if k < 0.3:
+            sc.add(S.Sphere(tuple(float(x) for x in rng.randint(-8, 9, 3) + np.array([0, 8, 0])), float(rng.choice([0.25, 0.5, 1.0])), _material(rng)))
+        elif k < 0.8:
+            o, u, v = _axis_rectangle(rng, -8, 8)
+            u = tuple(x / 4.0 for x in u)
+            v = tuple(x / 4.0 for x in v)
+            sc.add(S.Plane((o[0], o[1] + 8.0, o[2]), u, v, _material(rng)))
+        else:
+            o = tuple(float(x) for x in rng.uniform(-8.0, 8.0, 3) + np.array([0.0, 8.0, 0.0]))
+            u = rng.uniform(-1.5, 1.5, 3)
+            v = np.cross(u, rng.uniform(-1.5, 1.5, 3))
+            sc.add(S.Plane(o, tuple(float(x) for x in u), tuple(float(x) for x in v), _material(rng)))
+        if i % 50 == 49:   # a copy of a recent primitive
+            if sc.planes and rng.rand() < 0.5:
+                src = sc.planes[-1]
+                sc.add(S.Plane(src.origin, src.u, src.v, _material(rng)))
+            elif sc.spheres:
+                src = sc.spheres[-1]
+                sc.add(S.Sphere(src.origin, src.radius, _material(rng)))
+    osc = oracle.OracleScene(sc)
+    ref_ids = osc.primary_ids(oracle.options(), 2)
+    out = {}
+    for accel in (1, 2):
+        with binding.PtGpu(accel=accel, max_depth=4) as gpu:
+            gpu.upload_scene(sc)
+            ids = gpu.primary_ids(2)
+            gpu.render(2)
+            out[accel] = (ids, gpu.read_pixels32()[0], gpu.stats()["rays"])
+    assert np.array_equal(out[1][0], ref_ids) and np.array_equal(out[2][0], ref_ids)
+    assert out[1][2] == out[2][2] and np.array_equal(out[1][1], out[2][1])
