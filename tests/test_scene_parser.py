@@ -218,3 +218,32 @@ def test_hdr_loader_on_the_reference_sky():
     got = H.load_hdr(REF_HDR)
     assert got.shape == (512, 1024, 3) and np.isfinite(got).all() and got.min() >= 0.0
     assert np.array_equal(got, _rgbe_decode_reference(REF_HDR))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scenes_survive_text(binding, seed):
+    """Random scenes (the generator of the GPU fuzz test) written in the `.scene` dialect and read back by the C++
+    parser give the same primitive tables, camera and sky bit for bit; so does the C++ writer's own output."""
+    from test_gpu_fuzz import random_scene
+    sc, _, _ = random_scene(seed)
+    plain = S.Material.physically((0.5, 0.5, 0.5), 0.5, 0.0)
+    for prim in sc.spheres + sc.planes:          # the grammar has no Mirror / None
+        if prim.material.kind in (S.MAT_MIRROR, S.MAT_NONE):
+            prim.material = plain
+    if sc.sky.kind == S.SKY_HDRI:                # a texture in memory has no path to print
+        sc.sky = S.Sky.constant((0.25, 0.5, 0.75))
+    sc.image_settings.sub_pixel_sampling = True  # the only value the reference parser can produce
+    want = binding.SceneDesc(sc)
+    p = H.parse_scene(S.to_text(sc))
+    assert (p.desc.width, p.desc.height) == (sc.image_settings.width, sc.image_settings.height)
+    cam_got, cam_want = bytes(p.desc.camera), bytes(want.desc.camera)
+    if sc.camera.tone_mapping != S.TONE_EXPOSURE:   # clamp / reinhard carry no exposure value in the text
+        off = type(p.desc.camera).exposure.offset
+        cam_got, cam_want = cam_got[:off] + cam_got[off + 4:], cam_want[:off] + cam_want[off + 4:]
+    assert cam_got == cam_want
+    for got, ref in zip((p.spheres, p.planes, p.emissive_spheres, p.emissive_planes), want.arrays):
+        assert got.tobytes() == ref.tobytes()
+    q = H.parse_scene(p.write())
+    for a, b in zip((q.spheres, q.planes, q.emissive_spheres, q.emissive_planes), (p.spheres, p.planes, p.emissive_spheres, p.emissive_planes)):
+        assert a.tobytes() == b.tobytes()
+    assert bytes(q.desc.camera) == bytes(p.desc.camera)
