@@ -169,3 +169,31 @@ def test_random_soup_bvh_equals_linear_scan(binding, oracle, seed):
             out[accel] = (ids, gpu.read_pixels32()[0], gpu.stats()["rays"])
     assert np.array_equal(out[1][0], ref_ids) and np.array_equal(out[2][0], ref_ids)
     assert out[1][2] == out[2][2] and np.array_equal(out[1][1], out[2][1])
+
+
+@pytest.mark.parametrize("depth", [8, 11])
+def test_glass_everywhere_deep_tree(binding, oracle, depth):
+    """Nothing but glass: every hit branches in two, so the levels hold many records per sample (dozens at the deepest) and the queue
+    levels have to grow; the deepest levels see the NaN directions of total internal reflection."""
+    sc = S.Scene(
+        image_settings=S.ImageSettings(24, 18, True),
+        camera=S.Camera((0.0, 3.0, 12.0), (0.0, 3.0, 0.0), (0.0, 1.0, 0.0), 8.0, 6.0, 4.0, S.TONE_EXPOSURE, 0.7, 100.0),
+        sky=S.Sky.constant((0.9, 0.8, 0.7)),
+    )
+    sc.add(S.Plane((-8.0, 0.0, 8.0), (16.0, 0.0, 0.0), (0.0, 0.0, -16.0), S.Material.translucent(1.3)))
+    sc.add(S.Plane((-8.0, 0.0, -6.0), (16.0, 0.0, 0.0), (0.0, 12.0, 0.0), S.Material.translucent(1.7)))
+    sc.add(S.Sphere((0.0, 3.0, 0.0), 3.0, S.Material.translucent(1.5)))
+    sc.add(S.Sphere((0.0, 3.0, 0.0), 2.0, S.Material.translucent(1.2)))
+    sc.add(S.Sphere((0.5, 3.0, 0.5), 0.8, S.Material.translucent(2.0)))
+    sc.add(S.Sphere((-3.5, 2.0, 2.0), 1.5, S.Material.translucent(1.5)))
+    sc.add(S.Sphere((3.5, 2.0, 2.0), 1.5, S.Material.emissive((3.0, 2.0, 1.0))))
+    osc = oracle.OracleScene(sc)
+    r32, r8, rays = osc.render(oracle.options(max_depth=depth), 2)
+    for accel in (1, 2):
+        with binding.PtGpu(accel=accel, max_depth=depth) as gpu:
+            gpu.upload_scene(sc)
+            gpu.render(2)
+            p32, _ = gpu.read_pixels32()
+            st = gpu.stats()
+        assert st["rays"] == rays and np.array_equal(p32, r32), accel
+    assert rays > 24 * 18 * 2 * 2 * depth   # (far more than one ray per level: the tree does branch)
