@@ -70,6 +70,7 @@ def main() -> None:
                          "room: closed diffuse room at max_depth 16 (queue compaction)")
     ap.add_argument("--grid", type=int, default=1000, help="quads: rectangles per side")
     ap.add_argument("--fused", type=int, default=-1)
+    ap.add_argument("--accel", type=int, default=0, help="0 = library choice (BVH above 192 primitives), 1 = linear scan, 2 = BVH")
     ap.add_argument("--batch", type=int, default=0, help="samples per pixel per pipeline pass (0 = library default)")
     ap.add_argument("--passes", type=int, default=-1,
                     help="pipeline passes in flight; 0 = library default (2); -1 = 1 for sample/room, so that the per-kernel "
@@ -116,7 +117,8 @@ def main() -> None:
     if args.passes < 0:
         args.passes = 0 if args.workload == "quads" else 1
     gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, max_depth=args.max_depth,
-                        fuse_trace_shade=args.fused, samples_per_batch=args.batch, concurrent_passes=args.passes, profile_events=0 if args.no_events else 1)
+                        fuse_trace_shade=args.fused, samples_per_batch=args.batch, concurrent_passes=args.passes, accel=args.accel,
+                        profile_events=0 if args.no_events else 1)
     gpu.upload_scene(sc)
     for _ in range(args.warmup):
         gpu.render(args.spp_per_step)
@@ -143,7 +145,7 @@ def main() -> None:
         # the same steps with the library's default of two passes in flight (no per-kernel events)
         gpu.close()
         gpu = binding.PtGpu(device=local_rank, max_depth=args.max_depth, fuse_trace_shade=args.fused, samples_per_batch=args.batch,
-                            concurrent_passes=0, profile_events=0)
+                            concurrent_passes=0, accel=args.accel, profile_events=0)
         gpu.upload_scene(sc)
         for _ in range(args.warmup):
             gpu.render(args.spp_per_step)

@@ -635,7 +635,10 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     sc.circle_of_confusion = 22.0f / h->cfg.lens_aperture;  // src/tracer.rs:181
 
     // ---- acceleration structure
-    bool want_bvh = h->cfg.accel == PT_ACCEL_BVH || (h->cfg.accel == PT_ACCEL_AUTO && n_sph + n_pl > 48);
+    // Automatic choice: the fused linear-scan kernels stay ahead of the BVH pipeline (separate trace kernel, dependent
+    // node fetches) up to about 200 primitives - measured on the closed room with N spheres at 1080p, depth 8:
+    // 27 primitives 21.8 vs 7.6 Grays/s, 87: 11.6 vs 6.9, 167: 7.4 vs 6.4.
+    bool want_bvh = h->cfg.accel == PT_ACCEL_BVH || (h->cfg.accel == PT_ACCEL_AUTO && n_sph + n_pl > 192);
     h->bvh_nodes = h->bvh_leaf_prims = 0;
     h->lds_bytes = 0;
     if (want_bvh && n_sph + n_pl > 0) {
