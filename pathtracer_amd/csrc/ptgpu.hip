@@ -244,19 +244,20 @@ int alloc_levels(PtHandle *h) {
     const int D = h->cfg.max_depth;
     h->n_levels = D + 1;
     const uint32_t branch_cap = h->growth;
-    // samples per pixel per pass: about 16M records at level 0 (fewer, larger launches), bounded by a
+    // samples per pixel per pass: about 32M records at level 0 (fewer, larger launches), bounded by a
     // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
     uint32_t b = h->cfg.samples_per_batch;
-    // (16M records at level 0: measured +2 % over 8M on the sample scene, +15 % on BVH scenes, where a launch ends
-    // with a few rays that walk hundreds of nodes and longer launches dilute that)
-    const uint64_t target = 16u << 20;
+    // (measured on the sample scene at 1080p, one pass in flight: 8M records 24.1, 16M 25.3, 32M 26.3, 64M 27.8 Grays/s -
+    // every kernel boundary drains the chip once; with two passes in flight the steps are 28.4 / 28.7 / 29.0.  BVH
+    // scenes gain more: a launch ends with a few rays that walk hundreds of nodes and longer launches dilute that)
+    const uint64_t target = 32u << 20;
     if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
     const uint64_t rec_bytes = Level::RECORD_BYTES;
-    const uint64_t budget = 80ull << 30;  // of the 288 GB of an MI355X
+    const uint64_t budget = 96ull << 30;  // of the 288 GB of an MI355X
     for (;;) {
         uint64_t total = 0;
         for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4 * pipes_wanted(h);
