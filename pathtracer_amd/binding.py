@@ -91,6 +91,7 @@ def load_library() -> C.CDLL:
     lib.ptgpu_sync.argtypes = [H]
     lib.ptgpu_read_pixels32.argtypes = [H, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.ptgpu_read_pixels8.argtypes = [H, C.c_void_p]
+    lib.ptgpu_present_pixels8.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.ptgpu_render_primary_ids.argtypes = [H, C.c_uint32, C.c_void_p]
     lib.ptgpu_device_pixels32.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.ptgpu_set_num_samples.argtypes = [H, C.c_uint64]
@@ -111,7 +112,8 @@ def load_library() -> C.CDLL:
     lib.ptgpu_selftest_gamma.argtypes = [H, C.POINTER(C.c_uint64)]
     for name in ("ptgpu_create", "ptgpu_upload_scene", "ptgpu_clear", "ptgpu_render", "ptgpu_sync", "ptgpu_read_pixels32",
                  "ptgpu_read_pixels8", "ptgpu_render_primary_ids", "ptgpu_device_pixels32", "ptgpu_set_num_samples",
-                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32", "ptgpu_selftest_gamma"):
+                 "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32", "ptgpu_selftest_gamma",
+                 "ptgpu_present_pixels8"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -227,6 +229,14 @@ class PtGpu:
         out = np.empty((self.height, self.width, 3), dtype=np.uint8)
         self._chk(self.lib.ptgpu_read_pixels8(self.h, out.ctypes.data))
         return out
+
+    def present_pixels8(self) -> np.ndarray:
+        """The display bytes as a view of the library's own page-locked buffer (valid until the next present / upload /
+        close): what a window loop hands to glDrawPixels every frame."""
+        p = C.c_void_p()
+        self._chk(self.lib.ptgpu_present_pixels8(self.h, C.byref(p)))
+        buf = (C.c_uint8 * (self.height * self.width * 3)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
 
     def primary_ids(self, sample_index: int = 0) -> np.ndarray:
         out = np.empty((self.height, self.width), dtype=np.uint32)

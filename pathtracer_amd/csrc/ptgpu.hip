@@ -58,6 +58,7 @@ struct PtHandle {
     // accumulators
     uint32_t *d_pixels32 = nullptr;
     uint8_t *d_pixels8 = nullptr;
+    uint8_t *h_pixels8 = nullptr;  // page-locked host copy handed out by ptgpu_present_pixels8 (sized for the current scene)
     uint32_t *d_ids = nullptr;
     uint64_t num_samples = 0;      // what pixels8 divides by (global count after a multi-GPU combine)
     uint64_t local_samples = 0;    // samples per pixel this handle rendered since clear
@@ -145,6 +146,7 @@ void free_scene(PtHandle *h) {
     dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
     dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always);
     dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
+    if (h->h_pixels8) { (void)hipHostFree(h->h_pixels8); h->h_pixels8 = nullptr; }
     free_levels(h);
     dev_free(h->d_ctr); dev_free(h->d_flags);
     h->pending.clear();
@@ -767,6 +769,17 @@ int ptgpu_read_pixels8(PtHandle *h, uint8_t *out) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, h->d_pixels8, n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+int ptgpu_present_pixels8(PtHandle *h, const uint8_t **pixels) {
+    if (!h || !pixels) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    const uint32_t n = h->sc.width * h->sc.height * 3;
+    if (!h->h_pixels8) HIPCHK(h, hipHostMalloc((void **)&h->h_pixels8, n, hipHostMallocDefault));
+    int rc = ptgpu_read_pixels8(h, h->h_pixels8);
+    if (rc) return rc;
+    *pixels = h->h_pixels8;
     return PT_OK;
 }
 

@@ -76,6 +76,8 @@ int Renderer::read(Backbuffer &bb) {
     return ptgpu_read_pixels8(h_, bb.pixels8.data());
 }
 
+int Renderer::present(const uint8_t **pixels8) { return h_ ? ptgpu_present_pixels8(h_, pixels8) : PT_ERR_INVALID_ARGUMENT; }
+
 // ---- Radiance .hdr (RGBE) --------------------------------------------------------------------------------
 // What stb_image's HDR path does for a 3-component float load (the reference calls stb_image::image::load,
 // src/content.rs:17): header "#?RADIANCE"/"#?RGBE", FORMAT=32-bit_rle_rgbe, "-Y h +X w", scanlines either flat

@@ -144,6 +144,8 @@ public:
     int clear();                                   // Backbuffer::clear
     int render(uint32_t n_samples = 1);            // n frames of process(tile) x tiles + wait()
     int read(Backbuffer &bb);                      // pixels32, pixels8, num_samples
+    int present(const uint8_t **pixels8);          // what the window loop hands to glDrawPixels every frame (src/window.rs:205-210):
+                                                   // the display bytes in the library's page-locked buffer, valid until the next call
     int stats(PtStats &st);
     const char *last_error() const;
     PtHandle *handle() { return h_; }

@@ -68,14 +68,17 @@ int main(int argc, char **argv) {
     uint32_t per_frame = frames ? (spp + frames - 1) / frames : spp;
     uint32_t done = 0;
     Backbuffer bb;
+    const uint8_t *display = nullptr;
     while (done < spp) {
         uint32_t n = std::min(per_frame, spp - done);
         auto t0 = std::chrono::steady_clock::now();
-        if ((rc = r.render(n)) || (rc = r.read(bb))) { std::fprintf(stderr, "render failed (%d): %s\n", rc, r.last_error()); return 4; }
+        // a frame = the render call plus the display bytes, like process(tile) x tiles, wait(), glDrawPixels (src/window.rs:166-210)
+        if ((rc = r.render(n)) || (rc = r.present(&display))) { std::fprintf(stderr, "render failed (%d): %s\n", rc, r.last_error()); return 4; }
         auto t1 = std::chrono::steady_clock::now();
         std::printf("frame_time = %f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
         done += n;
     }
+    if ((rc = r.read(bb))) { std::fprintf(stderr, "readback failed (%d): %s\n", rc, r.last_error()); return 4; }
     PtStats st;
     r.stats(st);
     std::printf("%ux%u, %llu spp, %llu rays\n", bb.width, bb.height, (unsigned long long)bb.num_samples, (unsigned long long)st.rays);

@@ -401,3 +401,15 @@ def test_axis_aligned_rectangles_short_test(binding, oracle):
             gpu.upload_scene(sc)
             ids = gpu.primary_ids(1)
         assert np.array_equal(ids, osc.primary_ids(oracle.options(sub_pixel_override=jitter), 1))
+
+
+def test_present_gives_the_display_bytes(binding):
+    """The window loop's per-frame readback (Backbuffer.pixels8, src/window.rs:205-210) through the library's own
+    page-locked buffer: the same bytes as ptgpu_read_pixels8, frame after frame and after a new scene of another size."""
+    with binding.PtGpu() as gpu:
+        for w, h_ in ((96, 64), (40, 56)):
+            gpu.upload_scene(S.sample_scene(w, h_, camera_width=5.0 * w / h_))
+            for _ in range(3):
+                gpu.render(1)
+                shown = gpu.present_pixels8().copy()
+                assert shown.shape == (h_, w, 3) and np.array_equal(shown, gpu.read_pixels8())
