@@ -32,7 +32,7 @@ struct Pipe {
     hipEvent_t resolved = nullptr;     // recorded after the pass has added its samples to the accumulator
     bool resolved_pending = false;
     std::vector<Level> levels;
-    std::vector<void *> level_allocs;
+    std::vector<std::pair<void *, size_t>> level_allocs;  // (block, bytes) of each queue level
     uint32_t *d_counts = nullptr;      // [(n_levels + 1) * NSHARD * CSTRIDE]: per level, then the shadow-ray row
     uint2 *d_bvh_spill = nullptr;
     DevScene sc{};                     // the handle's scene with this pipe's spill area
@@ -45,6 +45,7 @@ struct PtHandle {
     std::string error;
 
     bool have_scene = false;
+    std::vector<std::pair<void *, size_t>> level_pool;  // queue level blocks between free_levels and the next alloc_levels
     DevScene sc{};
     // device scene buffers
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
@@ -125,9 +126,17 @@ void dev_free(T *&p) {
     p = nullptr;
 }
 
+void drain_level_pool(PtHandle *h) {
+    for (auto &a : h->level_pool) (void)hipFree(a.first);
+    h->level_pool.clear();
+}
+
 void free_levels(PtHandle *h) {
     for (Pipe &p : h->pipes) {
-        for (void *a : p.level_allocs) (void)hipFree(a);
+        // Blocks go to the handle's pool, not back to the driver: the next alloc_levels (a re-upload of a scene of the
+        // same size, or levels that grew) takes blocks of the sizes it needs from there and frees the rest.  Freeing and
+        // allocating tens of GiB takes the HIP runtime seconds at times (measured: 1-5 s for 65 GiB).
+        for (auto &a : p.level_allocs) h->level_pool.push_back(a);
         p.level_allocs.clear();
         p.levels.clear();
         if (p.d_counts) { h->device_bytes -= (uint64_t)(h->n_levels + 2) * NSHARD * CSTRIDE * 4; }
@@ -297,15 +306,26 @@ int alloc_levels(PtHandle *h) {
             // one allocation per level, carved into the SoA arrays (16-byte arrays first)
             size_t bytes = n * rec_bytes;
             char *base = nullptr;
-            HIPCHK(h, hipMalloc((void **)&base, bytes));
+            for (size_t k = 0; k < h->level_pool.size(); ++k)
+                if (h->level_pool[k].second == bytes) {
+                    base = (char *)h->level_pool[k].first;
+                    h->level_pool.erase(h->level_pool.begin() + (long)k);
+                    break;
+                }
+            if (!base && hipMalloc((void **)&base, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                drain_level_pool(h);   // the pooled blocks of other sizes may be what is in the way
+                HIPCHK(h, hipMalloc((void **)&base, bytes));
+            }
             h->device_bytes += bytes;
             h->level_bytes += bytes;
-            pipe.level_allocs.push_back(base);
+            pipe.level_allocs.push_back({base, bytes});
             L.base = base;
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_shard_caps, caps.data(), caps.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    drain_level_pool(h);   // blocks of sizes no level has any more
     return PT_OK;
 }
 
@@ -526,6 +546,7 @@ void ptgpu_destroy(PtHandle *h) {
     (void)hipSetDevice(h->device);
     for (Pipe &p : h->pipes) if (p.stream) (void)hipStreamSynchronize(p.stream);
     free_scene(h);
+    drain_level_pool(h);
     for (Pipe &p : h->pipes) if (p.resolved) (void)hipEventDestroy(p.resolved);
     for (int q = 1; q < PT_MAX_PIPES; ++q) if (h->pipes[q].stream) (void)hipStreamDestroy(h->pipes[q].stream);
     for (auto &s : h->spans) { (void)hipEventDestroy(s.start); (void)hipEventDestroy(s.stop); }
