@@ -329,14 +329,15 @@ int alloc_levels(PtHandle *h) {
     return PT_OK;
 }
 
-// Blocks of the tile kernels (grid-stride over wave-tiles).  Measured on the 1080p sample scene: 2048 blocks (all
-// resident, ~6 tiles per wave) is 7 % slower than 8192 (1-2 tiles per wave, the dispatcher balances uneven tiles);
-// beyond 16k the empty blocks start to cost.  PTGPU_GRID overrides it (tuning only).
-static int grid_tiles() {
-    static int g = [] { const char *e = getenv("PTGPU_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8192; }();
-    return g;
+// Blocks of the tile kernels (grid-stride over wave-tiles).  Measured on the sample scene: at 1080p with 8 spp per pass
+// 2048 blocks (all resident, ~6 tiles per wave) is 7 % slower than 8192 (1-2 tiles per wave, the dispatcher balances
+// uneven tiles); with 16 spp per pass 16384 is another 1 % ahead, while a 1-spp pass of a 1024x1024 image loses 6 %
+// with that many mostly empty blocks.  PTGPU_GRID overrides it (tuning only).
+static int grid_tiles(uint64_t level0_records) {
+    static int g = [] { const char *e = getenv("PTGPU_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    return g ? g : (level0_records >= (16u << 20) ? 16384 : 8192);
 }
-#define GRID_TILES grid_tiles()
+#define GRID_TILES grid_tiles(S)
 
 int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_first) {
     const uint32_t P = h->sc.width * h->sc.height;
