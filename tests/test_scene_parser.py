@@ -247,3 +247,19 @@ def test_random_scenes_survive_text(binding, seed):
     for a, b in zip((q.spheres, q.planes, q.emissive_spheres, q.emissive_planes), (p.spheres, p.planes, p.emissive_spheres, p.emissive_planes)):
         assert a.tobytes() == b.tobytes()
     assert bytes(q.desc.camera) == bytes(p.desc.camera)
+
+
+def test_procedural_quad_field_survives_text(binding):
+    """The 1M-rectangle stress scene of the benchmark is generated from a seed; written as `.scene` text (here at
+    100 x 100 rectangles + 100 spheres, ~2 MB) and read back by the C++ parser it gives the same tables bit for bit, so
+    the Rust host can load the same workload from a file."""
+    import time
+    sc = S.quad_field_scene(64, 48, grid=100, n_spheres=100)
+    text = S.to_text(sc)
+    t = time.perf_counter()
+    p = H.parse_scene(text)
+    dt = time.perf_counter() - t
+    want = binding.SceneDesc(sc)
+    for got, ref in zip((p.spheres, p.planes, p.emissive_spheres, p.emissive_planes), want.arrays):
+        assert got.tobytes() == ref.tobytes()
+    assert len(p.planes) == 100 * 100 and len(text) / dt > 5e6   # (the parser reads tens of MB per second)
