@@ -197,3 +197,46 @@ def test_glass_everywhere_deep_tree(binding, oracle, depth):
             st = gpu.stats()
         assert st["rays"] == rays and np.array_equal(p32, r32), accel
     assert rays > 24 * 18 * 2 * 2 * depth   # (far more than one ray per level: the tree does branch)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_call_sequences(binding, seed):
+    """The handle as a state machine: random sequences of upload / clear / render(n) / reads / sync on one handle must
+    leave exactly what a fresh handle renders in one call with the same number of samples since the last clear or
+    upload, whatever the pass size, the number of passes in flight and the scene sizes uploaded in between."""
+    rng = np.random.RandomState(4000 + seed)
+    scenes = [S.sample_scene(40, 30, camera_width=20.0 / 3.0), S.sample_scene(64, 24, camera_width=40.0 / 3.0), random_scene(seed)[0]]
+    cfg = dict(samples_per_batch=int(rng.randint(0, 4)), concurrent_passes=int(rng.randint(1, 4)), max_depth=int(rng.randint(2, 6)),
+               accel=int(rng.choice([0, 2])))
+    with binding.PtGpu(**cfg) as gpu:
+        cur, n = None, 0
+        for _ in range(30):
+            op = rng.randint(0, 8)
+            if cur is None or op == 0:
+                cur = scenes[rng.randint(0, len(scenes))]
+                gpu.upload_scene(cur)
+                n = 0
+            elif op == 1:
+                gpu.clear()
+                n = 0
+            elif op <= 4:
+                k = int(rng.randint(1, 6))
+                gpu.render(k)
+                n += k
+            elif op == 5:
+                p32, ns = gpu.read_pixels32()
+                assert ns == n
+            elif op == 6:
+                assert gpu.present_pixels8().shape == (cur.image_settings.height, cur.image_settings.width, 3)
+            else:
+                gpu.sync()
+        got, ns = gpu.read_pixels32()
+        got8 = gpu.read_pixels8()
+    assert ns == n
+    with binding.PtGpu(max_depth=cfg["max_depth"]) as fresh:
+        fresh.upload_scene(cur)
+        if n:
+            fresh.render(n)
+        want, _ = fresh.read_pixels32()
+        want8 = fresh.read_pixels8()
+    assert np.array_equal(got, want) and np.array_equal(got8, want8)
