@@ -99,7 +99,7 @@ def test_full_size_1080p_properties(binding, oracle):
     assert inner.sum() > 1000 and np.all(full[inner] == 6 * 255)
 
 
-@pytest.mark.parametrize("width,height,spp", [(1920, 1080, 4), (3840, 2160, 1)])
+@pytest.mark.parametrize("width,height,spp", [(1920, 1080, 4), (3840, 2160, 1), (7680, 4320, 1)])
 def test_full_size_pixels_bit_exact(binding, oracle, width, height, spp):
     """The benchmark's own image sizes, pixel for pixel: the oracle's worker pool (counter RNG, deterministic math: the
     result does not depend on which thread renders which tile) finishes a few samples per pixel in seconds."""
