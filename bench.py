@@ -219,6 +219,20 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": round(alg / n_launch, 1),
                 "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
             }
+            # what actually binds the fused kernel: vector instruction issue.  Instruction counts per launch come from the
+            # committed counter run of the same command (profiles/), the duration is this run's; the peak is the measured
+            # issue rate of independent wave64 v_fma_f32 on this chip (profiles/micro/valu_exec_mask.hip).
+            cpath = os.path.join(ROOT, "profiles", {"sample": "r01_counters.json", "room": "r01_room_counters.json",
+                                                    "quads": "r01_quads_counters.json"}[args.workload])
+            try:
+                ctr = json.load(open(cpath)).get(name, {})
+                insts = ctr["SQ_INSTS_VALU"]["per_launch"]
+                lanes = ctr["SQ_THREAD_CYCLES_VALU"]["per_launch"] / insts / 64.0
+                rate = insts / (ms / n_launch * 1e-3) / 1e9
+                out["valu"] = {"wave_insts_per_launch": round(insts), "achieved": round(rate, 1), "peak": 923.0,
+                               "unit": "G wave-instructions/s", "frac": round(rate / 923.0, 3), "lane_utilisation": round(lanes, 3)}
+            except Exception:
+                pass
             if name == "trace":
                 out["roofline"]["note"] = ("64 bytes per traversal step are priced whether they come from HBM or from a cache; most node "
                                            "fetches are cache hits, so this rate can exceed the HBM peak - `traffic` is what HBM saw")
