@@ -1,0 +1,16 @@
+"""One-off soak of the randomised parity test over many more seeds than the suite runs: python profiles/debug/soak.py FIRST COUNT"""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import test_gpu_fuzz as F
+from oracle import ptref
+from pathtracer_amd import binding
+binding.load_library(); ptref.lib()
+first, count = int(sys.argv[1]), int(sys.argv[2])
+t = time.time(); bad = []
+for seed in range(first, first + count):
+    try:
+        F.test_random_scene_three_ways(binding, ptref, seed)
+    except AssertionError as e:
+        bad.append(seed); print("MISMATCH seed", seed, str(e)[:200], flush=True)
+    if (seed - first) % 500 == 499: print(seed, f"{time.time()-t:.0f} s", flush=True)
+print("done", count, "seeds,", len(bad), "mismatches", bad[:20], flush=True)
