@@ -1,4 +1,5 @@
-"""One-off soak of the randomised parity test over many more seeds than the suite runs: python profiles/debug/soak.py FIRST COUNT"""
+"""One-off soak of a randomised test over many more seeds than the suite runs:
+python profiles/debug/soak.py FIRST COUNT [scenes|calls]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import test_gpu_fuzz as F
@@ -6,10 +7,12 @@ from oracle import ptref
 from pathtracer_amd import binding
 binding.load_library(); ptref.lib()
 first, count = int(sys.argv[1]), int(sys.argv[2])
+which = sys.argv[3] if len(sys.argv) > 3 else "scenes"
 t = time.time(); bad = []
 for seed in range(first, first + count):
     try:
-        F.test_random_scene_three_ways(binding, ptref, seed)
+        if which == "scenes": F.test_random_scene_three_ways(binding, ptref, seed)
+        else: F.test_random_call_sequences(binding, seed)
     except AssertionError as e:
         bad.append(seed); print("MISMATCH seed", seed, str(e)[:200], flush=True)
     if (seed - first) % 500 == 499: print(seed, f"{time.time()-t:.0f} s", flush=True)
