@@ -1,5 +1,5 @@
 """One-off soak of a randomised test over many more seeds than the suite runs:
-python profiles/debug/soak.py FIRST COUNT [scenes|calls]"""
+python profiles/debug/soak.py FIRST COUNT [scenes|calls|soups]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import test_gpu_fuzz as F
@@ -12,7 +12,8 @@ t = time.time(); bad = []
 for seed in range(first, first + count):
     try:
         if which == "scenes": F.test_random_scene_three_ways(binding, ptref, seed)
-        else: F.test_random_call_sequences(binding, seed)
+        elif which == "calls": F.test_random_call_sequences(binding, seed)
+        else: F.test_random_soup_bvh_equals_linear_scan(binding, ptref, seed)
     except AssertionError as e:
         bad.append(seed); print("MISMATCH seed", seed, str(e)[:200], flush=True)
     if (seed - first) % 500 == 499: print(seed, f"{time.time()-t:.0f} s", flush=True)
