@@ -115,6 +115,9 @@ float ptref_math_eval(int32_t mode, int32_t fn, float a, float b) {
     case 3: return m_exp(mode, a);
     case 4: return m_acos(mode, a);
     case 5: return m_atan2(mode, a, b);
+    case 6: return sqrtf(a);            /* IEEE: the host's is correctly rounded */
+    case 7: return a / b;
+    case 8: { uint32_t u; memcpy(&u, &a, 4); return ptref_random32_from_u32(u); }
     default: return 0.0f;
     }
 }

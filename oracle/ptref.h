@@ -119,7 +119,7 @@ typedef struct {
 uint32_t ptref_xorshift32_next(uint32_t *state);                       /* common.rs:28-36 */
 float ptref_random32_from_u32(uint32_t r);                             /* common.rs:38-41 */
 uint32_t ptref_counter_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t dim);
-float ptref_math_eval(int32_t math_mode, int32_t fn, float a, float b); /* fn: 0 sin 1 cos 2 pow 3 exp 4 acos 5 atan2 */
+float ptref_math_eval(int32_t math_mode, int32_t fn, float a, float b); /* fn: 0 sin 1 cos 2 pow 3 exp 4 acos 5 atan2 6 sqrt 7 a/b 8 random32(bits of a) */
 void ptref_math_eval_array(int32_t math_mode, int32_t fn, const float *a, const float *b, float *out, uint64_t n);
 float ptref_sqrtf_ieee(float x);
 

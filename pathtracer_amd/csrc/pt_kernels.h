@@ -931,6 +931,9 @@ __global__ void k_eval_math(int fn, const float *a, const float *b, float *out, 
         case 2: r = det::powf_(x, y); break;
         case 3: r = det::expf_(x); break;
         case 4: r = det::acosf_(x); break;
+        case 6: r = sqrt_ieee(x); break;     // the two basic operations the compiler expands into instruction sequences
+        case 7: r = x / y; break;
+        case 8: r = (float)f2u(x) / 4294967296.0f; break;   // random32 of the argument's bit pattern (common.rs:38-41)
         default: r = det::atan2f_(x, y); break;
         }
         out[i] = r;

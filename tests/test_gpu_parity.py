@@ -413,3 +413,19 @@ def test_present_gives_the_display_bytes(binding):
                 gpu.render(1)
                 shown = gpu.present_pixels8().copy()
                 assert shown.shape == (h_, w, 3) and np.array_equal(shown, gpu.read_pixels8())
+
+
+def test_basic_operations_match_the_host(binding, oracle):
+    """f32 square root and division compile to instruction sequences on the device (correctly rounded by default) and
+    the u32 -> (0,1] mapping of random32 is a division by 2^32: random bit patterns of every class against the host's
+    IEEE results, bit for bit (profiles/debug/math_exhaustive.py runs the same over all 2^32 arguments)."""
+    rng = np.random.RandomState(9)
+    a = rng.randint(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)
+    b = rng.randint(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)
+    near = (b & np.uint32(0x807FFFFF)) | (a & np.uint32(0x7F800000))   # same exponent as the dividend
+    fa = a.view(np.float32)
+    with binding.PtGpu() as gpu:
+        for fn, x, y in ((6, fa, None), (8, fa, None), (7, fa, b.view(np.float32)), (7, fa, near.view(np.float32))):
+            got = gpu.eval_math(fn, x, y)
+            ref = oracle.math_eval(oracle.MATH_DET, fn, x, y)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), fn
