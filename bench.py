@@ -59,7 +59,7 @@ def cpu_baseline(sc, budget_s: float, threads: int, note: str = "the same", warm
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=0, help="0 = 32: several pipeline passes per step, so that a step is ~10-30 ms and the one all-reduce of a multi-GPU run is small beside it")
     ap.add_argument("--width", type=int, default=1920)
