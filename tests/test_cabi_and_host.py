@@ -75,3 +75,11 @@ def test_scene_routing_like_the_parser():
     assert (len(sc.spheres), len(sc.planes), len(sc.emissive_spheres), len(sc.emissive_planes)) == (3, 6, 0, 1)
     # ids: spheres, emissive spheres, planes, emissive planes (reference src/scene.rs:266,280)
     assert sc.spheres[0].material.kind == S.MAT_TRANSLUCENT and sc.planes[2].origin == (-5.0, 0.0, -5.0)
+
+
+def test_header_is_plain_c99():
+    """The public header is consumed by C, cgo, bindgen: it must compile as strict C99 with nothing but <stdint.h>,
+    and so must the C host that the GPU test runs."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), src])

@@ -92,3 +92,25 @@ def test_ptcli_thin_lens_and_pfm_export(binding, tmp_path):
         gpu.render(3)
         p32, n = gpu.read_pixels32()
     assert np.array_equal(img, p32.reshape(48, 64, 3).astype(np.float32) / np.float32(3 * 255.0))
+
+
+def test_plain_c_host_renders_the_same(binding):
+    """tests/c/abi_smoke.c (C99, -pedantic, built by __graft_entry__.build()) drives the library through the public
+    header alone; its accumulator checksum must equal the same scene rendered through the ctypes binding."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "c", "abi_smoke")
+    r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    words = r.stdout.split()
+    got = dict(zip(words[0::2], (int(w) for w in words[1::2])))
+    sc = S.Scene(image_settings=S.ImageSettings(32, 24, True),
+                 camera=S.Camera((0.0, 2.0, 6.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 4.0, 3.0, 2.0, S.TONE_CLAMP, 1.0, 100.0),
+                 sky=S.Sky.constant((0.5, 0.6, 0.7)))
+    sc.add(S.Sphere((0.0, 1.0, 0.0), 1.0, S.Material.translucent(1.5)))
+    sc.add(S.Plane((-4.0, 0.0, 4.0), (8.0, 0.0, 0.0), (0.0, 0.0, -8.0), S.Material.physically((0.8, 0.7, 0.6), 0.5, 0.0)))
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(3)
+        p32, n = gpu.read_pixels32()
+        p8 = gpu.read_pixels8()
+    assert got["samples"] == n == 3 and got["sum"] == int(p32.astype(np.uint64).sum()) and got["first_byte"] == int(p8.reshape(-1)[0])
