@@ -945,18 +945,17 @@ int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, flo
     if (n == 0) return PT_OK;
     HIPCHK(h, hipSetDevice(h->device));
     float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIPCHK(h, hipMalloc((void **)&da, n * 4));
-    HIPCHK(h, hipMalloc((void **)&dout, n * 4));
-    HIPCHK(h, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
-    if (b) {
-        HIPCHK(h, hipMalloc((void **)&db, n * 4));
-        HIPCHK(h, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc((void **)&da, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dout, n * 4);
+    if (e == hipSuccess && b) e = hipMalloc((void **)&db, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_eval_math<<<(unsigned)std::min<uint64_t>(4096, (n + 255) / 256), 256, 0, h->stream>>>(fn, da, db, dout, n);
+        e = hipStreamSynchronize(h->stream);
     }
-    k_eval_math<<<(unsigned)std::min<uint64_t>(4096, (n + 255) / 256), 256, 0, h->stream>>>(fn, da, db, dout, n);
-    hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(da); (void)hipFree(dout);
-    if (db) (void)hipFree(db);
+    (void)hipFree(da); (void)hipFree(dout); (void)hipFree(db);   // (hipFree(nullptr) is a no-op)
     if (e != hipSuccess) return fail(h, PT_ERR_HIP, hipGetErrorString(e));
     return PT_OK;
 }
