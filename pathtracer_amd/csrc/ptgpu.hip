@@ -927,12 +927,14 @@ int ptgpu_selftest_gamma(PtHandle *h, uint64_t *mismatches) {
     HIPCHK(h, hipSetDevice(h->device));
     unsigned long long *d = nullptr, host = 0;
     HIPCHK(h, hipMalloc((void **)&d, 8));
-    HIPCHK(h, hipMemsetAsync(d, 0, 8, h->stream));
-    k_check_gamma<<<4096, 256, 0, h->stream>>>(h->sc.gamma_table, 0u, 0x3f800000u, d);          // +0 .. 1.0
-    k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x3f800001u, 0x3f810000u, d);    // just above 1
-    k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x80000000u, 0x80010000u, d);    // -0 and small negatives
-    k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x7f7f0000u, 0x7fc10000u, d);    // huge, inf, NaNs
-    hipError_t e = hipMemcpyAsync(&host, d, 8, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipMemsetAsync(d, 0, 8, h->stream);
+    if (e == hipSuccess) {
+        k_check_gamma<<<4096, 256, 0, h->stream>>>(h->sc.gamma_table, 0u, 0x3f800000u, d);          // +0 .. 1.0
+        k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x3f800001u, 0x3f810000u, d);    // just above 1
+        k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x80000000u, 0x80010000u, d);    // -0 and small negatives
+        k_check_gamma<<<64, 256, 0, h->stream>>>(h->sc.gamma_table, 0x7f7f0000u, 0x7fc10000u, d);    // huge, inf, NaNs
+        e = hipMemcpyAsync(&host, d, 8, hipMemcpyDeviceToHost, h->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(h, PT_ERR_HIP, hipGetErrorString(e));
