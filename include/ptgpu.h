@@ -34,7 +34,8 @@ typedef enum {
     PT_ERR_HIP = -3,              /* a HIP runtime call failed; see ptgpu_last_error */
     PT_ERR_NO_SCENE = -4,         /* render/read before ptgpu_upload_scene */
     PT_ERR_QUEUE_OVERFLOW = -5,   /* a ray queue level exceeded its capacity (glass branching); raise branch_capacity */
-    PT_ERR_OUT_OF_MEMORY = -6
+    PT_ERR_OUT_OF_MEMORY = -6,    /* device or host memory */
+    PT_ERR_INTERNAL = -7          /* an unexpected failure inside the library (caught before it could cross this boundary) */
 } PtStatus;
 
 typedef struct { float x, y, z; } PtVec3;
@@ -134,6 +135,11 @@ typedef struct {
     uint64_t device_bytes;                    /* device memory held by the handle */
     uint64_t queue_growth;                    /* queue level l holds min(2^l, queue_growth) records per sample (1 without glass) */
     uint64_t debug_cycles[8];                 /* per-phase shader cycles of the fused kernel; diagnostic builds only, else 0 */
+    uint64_t bvh_depth;                       /* levels of inner nodes in the 4-wide tree (a traversal stack holds at most 3 per level) */
+    uint64_t bvh_binary_depth;                /* depth of the binary SAH tree it was folded from (capped at 38) */
+    uint64_t bvh_forced_median_splits;        /* splits the builder took at the object median to stay under that cap */
+    uint64_t bvh_level_fold;                  /* 1: the 4-wide tree was folded level by level because folding by box area was too deep */
+    uint64_t queue_bytes;                     /* the part of device_bytes held by the ray queue levels */
 } PtStats;
 
 typedef struct PtHandle PtHandle;
@@ -181,12 +187,16 @@ int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples);
 int ptgpu_export_pixels32(PtHandle *h, void *dst_device);
 int ptgpu_import_pixels32(PtHandle *h, const void *src_device, uint64_t num_samples);
 /* The handle's hipStream_t (as void*), for event timing by the caller.  Everything a call of this library enqueues is
- * ordered on this stream by the time the call returns (a second, internal stream that carries every other pass is
- * joined into it at the end of ptgpu_render); work the caller enqueues here itself is not seen by that second stream
- * until ptgpu_sync. */
+ * ordered on this stream by the time the call returns (up to three more internal streams carry the other passes in
+ * flight, PtConfig.concurrent_passes, and are joined into it at the end of ptgpu_render); work the caller enqueues here
+ * itself is not seen by those streams until ptgpu_sync. */
 int ptgpu_stream(PtHandle *h, void **stream);
 
 int ptgpu_get_stats(PtHandle *h, PtStats *out);
+/* The acceleration structure ptgpu_upload_scene would build for this scene, built on the host only (no device is
+ * touched): fills the bvh_* fields of *out, zeroes the rest.  The reference has no such structure (find_scene_hit,
+ * src/scene.rs:263-297, scans every primitive); this is how a host or a test checks its size and depth bounds. */
+int ptgpu_bvh_build_stats(const PtSceneDesc *scene, PtStats *out);
 const char *ptgpu_last_error(PtHandle *h);
 
 /* What the Rust host computes with hmath before the scene reaches this library; provided for C/C++/

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("PTGPU_LIB", os.path.join(_HERE, "libptgpu.so"))  # ov
 PT_KERNEL_COUNT = 8
 KERNEL_NAMES = ["raygen", "trace", "shade", "trace_shade", "terminal", "gather", "resolve", "unused"]
 STATUS = {0: "PT_OK", -1: "PT_ERR_INVALID_ARGUMENT", -2: "PT_ERR_NO_DEVICE", -3: "PT_ERR_HIP", -4: "PT_ERR_NO_SCENE",
-          -5: "PT_ERR_QUEUE_OVERFLOW", -6: "PT_ERR_OUT_OF_MEMORY"}
+          -5: "PT_ERR_QUEUE_OVERFLOW", -6: "PT_ERR_OUT_OF_MEMORY", -7: "PT_ERR_INTERNAL"}
 ACCEL_AUTO, ACCEL_BRUTE_FORCE, ACCEL_BVH = 0, 1, 2
 
 
@@ -58,7 +58,9 @@ class PtConfig(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("records", C.c_uint64), ("terminal_records", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_leaf_prims", C.c_uint64), ("bvh_steps", C.c_uint64), ("kernel_launches", C.c_uint64 * PT_KERNEL_COUNT),
-                ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64), ("queue_growth", C.c_uint64), ("debug_cycles", C.c_uint64 * 8)]
+                ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64), ("queue_growth", C.c_uint64), ("debug_cycles", C.c_uint64 * 8),
+                ("bvh_depth", C.c_uint64), ("bvh_binary_depth", C.c_uint64), ("bvh_forced_median_splits", C.c_uint64),
+                ("bvh_level_fold", C.c_uint64), ("queue_bytes", C.c_uint64)]
 
 
 class PtGpuError(RuntimeError):
@@ -99,6 +101,8 @@ def load_library() -> C.CDLL:
     lib.ptgpu_export_pixels32.argtypes = [H, C.c_void_p]
     lib.ptgpu_import_pixels32.argtypes = [H, C.c_void_p, C.c_uint64]
     lib.ptgpu_get_stats.argtypes = [H, C.POINTER(PtStats)]
+    lib.ptgpu_bvh_build_stats.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtStats)]
+    lib.ptgpu_bvh_build_stats.restype = C.c_int
     lib.ptgpu_last_error.argtypes = [H]
     lib.ptgpu_last_error.restype = C.c_char_p
     lib.ptgpu_camera_new.argtypes = [PtVec3, PtVec3, PtVec3, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float,
@@ -168,6 +172,30 @@ class SceneDesc:
         d.emissive_spheres, d.n_emissive_spheres = (es.ctypes.data if len(es) else None), len(es)
         d.emissive_planes, d.n_emissive_planes = (ep.ctypes.data if len(ep) else None), len(ep)
         self.desc = d
+
+
+def bvh_build_stats(scene: S.Scene) -> dict:
+    """Size and depth of the BVH the library would build for `scene` (host only: works without a GPU)."""
+    sd = SceneDesc(scene)
+    st = PtStats()
+    rc = load_library().ptgpu_bvh_build_stats(C.byref(sd.desc), C.byref(st))
+    if rc != 0:
+        raise PtGpuError(rc, "ptgpu_bvh_build_stats failed")
+    return {k: int(getattr(st, k)) for k in ("bvh_nodes", "bvh_leaf_prims", "bvh_depth", "bvh_binary_depth",
+                                             "bvh_forced_median_splits", "bvh_level_fold")}
+
+
+def _stats_dict(st: PtStats) -> dict:
+    return {
+        "samples": st.samples, "rays": st.rays, "shadow_rays": st.shadow_rays, "records": st.records, "terminal_records": st.terminal_records, "bvh_nodes": st.bvh_nodes,
+        "bvh_leaf_prims": st.bvh_leaf_prims, "bvh_steps": st.bvh_steps, "device_bytes": st.device_bytes, "queue_growth": st.queue_growth,
+        "kernel_launches": {KERNEL_NAMES[k]: st.kernel_launches[k] for k in range(PT_KERNEL_COUNT)},
+        "kernel_ms": {KERNEL_NAMES[k]: st.kernel_ms[k] for k in range(PT_KERNEL_COUNT)},
+        "debug_cycles": [int(st.debug_cycles[k]) for k in range(8)],
+        "bvh_depth": st.bvh_depth, "bvh_binary_depth": st.bvh_binary_depth,
+        "bvh_forced_median_splits": st.bvh_forced_median_splits, "bvh_level_fold": st.bvh_level_fold,
+        "queue_bytes": st.queue_bytes,
+    }
 
 
 class PtGpu:
@@ -265,13 +293,7 @@ class PtGpu:
     def stats(self) -> dict:
         st = PtStats()
         self._chk(self.lib.ptgpu_get_stats(self.h, C.byref(st)))
-        return {
-            "samples": st.samples, "rays": st.rays, "shadow_rays": st.shadow_rays, "records": st.records, "terminal_records": st.terminal_records, "bvh_nodes": st.bvh_nodes,
-            "bvh_leaf_prims": st.bvh_leaf_prims, "bvh_steps": st.bvh_steps, "device_bytes": st.device_bytes, "queue_growth": st.queue_growth,
-            "kernel_launches": {KERNEL_NAMES[k]: st.kernel_launches[k] for k in range(PT_KERNEL_COUNT)},
-            "kernel_ms": {KERNEL_NAMES[k]: st.kernel_ms[k] for k in range(PT_KERNEL_COUNT)},
-            "debug_cycles": [int(st.debug_cycles[k]) for k in range(8)],
-        }
+        return _stats_dict(st)
 
     def selftest_gamma(self) -> int:
         n = C.c_uint64()

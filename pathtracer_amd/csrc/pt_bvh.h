@@ -36,7 +36,8 @@ static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 
 constexpr int32_t BVH_EMPTY = (int32_t)0x80000000;
 constexpr int BVH_BINARY_DEPTH = 38;   // depth cap of the binary tree the builder starts from
-constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 3, the folded tree is at most 20 deep
+constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 3 per level of the 4-wide tree, whose depth the builder
+                                       // keeps at or below BVH_STACK / 3 (BvhBuilder::build)
 #ifndef PT_BVH_LDS_ENTRIES
 #define PT_BVH_LDS_ENTRIES 8
 #endif
@@ -116,10 +117,16 @@ struct TravStack {
     uint2 *spill;   // sc.bvh_spill + global thread index
     __device__ __forceinline__ void put(int k, uint2 e) const {
         if (k < BVH_LDS_ENTRIES) lds[k * BVH_STACK_STRIDE] = e;
-        else spill[(size_t)(k - BVH_LDS_ENTRIES) * (BVH_TRAV_BLOCKS * BVH_STACK_STRIDE)] = e;
+        else {
+            // the builder bounds the depth so that k < BVH_STACK always; the clamp keeps a tree that broke that promise
+            // from writing outside the spill area (its image would be wrong, the process unharmed)
+            k = k < BVH_STACK ? k : BVH_STACK - 1;
+            spill[(size_t)(k - BVH_LDS_ENTRIES) * (BVH_TRAV_BLOCKS * BVH_STACK_STRIDE)] = e;
+        }
     }
     __device__ __forceinline__ uint2 get(int k) const {
         if (k < BVH_LDS_ENTRIES) return lds[k * BVH_STACK_STRIDE];
+        k = k < BVH_STACK ? k : BVH_STACK - 1;
         return spill[(size_t)(k - BVH_LDS_ENTRIES) * (BVH_TRAV_BLOCKS * BVH_STACK_STRIDE)];
     }
 };

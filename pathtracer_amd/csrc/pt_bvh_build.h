@@ -29,7 +29,10 @@ struct BvhBuilder {
     std::vector<uint32_t> prims;   // leaf primitive ids, in leaf order
     std::vector<float4> geom;      // the same primitives' geometry, 4 vectors each, id in the last word (device bvh_geom)
     std::vector<uint32_t> always;  // primitives tested for every ray
-    int max_depth_seen = 0;
+    int max_depth_seen = 0;        // depth of the binary tree (root = 0)
+    int depth4 = 0;                // levels of inner nodes of the 4-wide tree: a traversal holds at most 3 * depth4 stack entries
+    uint64_t forced_median_splits = 0;  // splits taken at the object median because SAH could have exceeded the depth cap
+    bool level_fold = false;       // the 4-wide tree was folded level by level (see fold) to bound its depth
 
     struct Box {
         double lo[3], hi[3];
@@ -120,8 +123,19 @@ struct BvhBuilder {
             return;
         }
         bn.reserve(idx.size());
+        max_depth_seen = 0;
+        forced_median_splits = 0;
         build_range(0, (uint32_t)idx.size(), 0);
+        // The traversal pushes up to three children per inner node on the way down, so its stack holds at most
+        // 3 * depth4 entries.  Folding by box area (fastest to traverse) gives no bound better than the binary depth
+        // cap; when such a tree would be too deep for the stack it is folded again level by level, which halves the
+        // binary depth: at most (BVH_BINARY_DEPTH + 1) / 2 = 19 levels, 57 entries.
+        level_fold = false;
         flatten();
+        if (3 * depth4 > BVH_STACK) {
+            level_fold = true;
+            flatten();
+        }
     }
 
     Box range_box(uint32_t first, uint32_t count) const {
@@ -141,6 +155,7 @@ struct BvhBuilder {
         // could otherwise exceed the traversal stack.
         const int remaining = BVH_BINARY_DEPTH - depth;
         bool force_median = remaining < 1 || (remaining < 40 && (uint64_t)count > ((uint64_t)BVH_MAX_LEAF << (remaining > 0 ? remaining - 1 : 0)));
+        if (force_median) ++forced_median_splits;
         Box cb; cb.reset();
         for (uint32_t i = first; i < first + count; ++i) cb.grow(&pcent[3 * (size_t)idx[i]]);
         int axis = 0;
@@ -228,9 +243,19 @@ struct BvhBuilder {
     }
 
     // Children of the 4-wide node rooted at binary node b: b's two children, then the inner one with the largest
-    // box is replaced by ITS two children, until there are four or only leaves are left.
+    // box is replaced by ITS two children, until there are four or only leaves are left.  With level_fold both of
+    // b's inner children are replaced instead (the grandchildren), so every inner child of the 4-wide node sits
+    // exactly two binary levels below it.
     int fold(int32_t b, int32_t out[4]) const {
         int n = 0;
+        if (level_fold) {
+            const int32_t two[2] = {bn[b].left, bn[b].right};
+            for (int k = 0; k < 2; ++k) {
+                if (bn[two[k]].left >= 0) { out[n++] = bn[two[k]].left; out[n++] = bn[two[k]].right; }
+                else out[n++] = two[k];
+            }
+            return n;
+        }
         out[n++] = bn[b].left;
         out[n++] = bn[b].right;
         while (n < 4) {
@@ -251,6 +276,10 @@ struct BvhBuilder {
         // bytes, a subtree is one contiguous run, and - leaves being emitted in the same order - so is its
         // geometry; rays that are close in space then share cache lines on the way down.
         std::vector<int32_t> inner_index(bn.size(), -1), order;
+        nodes.clear();
+        prims.clear();
+        geom.clear();
+        depth4 = 1;
         if (bn[0].left < 0) {  // a single leaf: wrap it in a root
             BvhNode root{};
             std::vector<int32_t> none;
@@ -261,16 +290,18 @@ struct BvhBuilder {
             pad_geom();
             return;
         }
-        std::vector<int32_t> todo{0};
+        std::vector<std::pair<int32_t, int>> todo{{0, 1}};  // (binary node, its level in the 4-wide tree)
         while (!todo.empty()) {
-            int32_t b = todo.back();
+            const int32_t b = todo.back().first;
+            const int level = todo.back().second;
             todo.pop_back();
+            depth4 = std::max(depth4, level);
             inner_index[b] = (int32_t)order.size();
             order.push_back(b);
             int32_t ch[4];
             int n = fold(b, ch);
             for (int k = n - 1; k >= 0; --k)
-                if (bn[ch[k]].left >= 0) todo.push_back(ch[k]);
+                if (bn[ch[k]].left >= 0) todo.push_back({ch[k], level + 1});
         }
         nodes.resize(order.size());
         for (size_t k = 0; k < order.size(); ++k) {

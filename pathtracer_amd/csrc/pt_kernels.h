@@ -138,6 +138,13 @@ __device__ __forceinline__ void wave_resolve(const Level &L, uint32_t shard, con
     i1 = shard * L.shard_cap + base + n0 + (uint32_t)__popcll(r.m1 & lt);
 }
 
+// A pass in which an append found a level full is void: nothing it computes is accumulated or counted, and the host
+// renders its samples again.  The wave whose reservation did not fit wrote no children, yet the shard's counter already
+// includes them, so the records behind that counter are whatever the memory held before - rays and parent links that
+// nobody wrote.  No kernel may consume them: every kernel of a pass returns at once when the pass's flag is already up
+// (it is raised by an EARLIER launch of the same stream, or by this one, whose stragglers then merely stop early).
+__device__ __forceinline__ bool pass_voided(const Level &L) { return __builtin_nontemporal_load(L.overflow) != 0u; }
+
 __device__ __forceinline__ uint32_t my_shard() { return (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (NSHARD - 1); }
 __device__ __forceinline__ uint32_t wave_global() { return blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t waves_in_grid() { return gridDim.x * (BLOCK / 64); }
@@ -195,6 +202,7 @@ __device__ __forceinline__ uint32_t pack_hit(uint32_t prim, int transition) {
 
 // ---- trace: reference src/scene.rs:263-297 ------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
+    if (pass_voided(L)) return;
     TileMap m = tile_map(L);
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
@@ -229,6 +237,7 @@ constexpr int DYN_STEPS = PT_DYN_STEPS;        // traversal steps between refill
 #endif
 __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc, Level L, Counters *ctr) {
     __shared__ uint32_t s_incl[NSHARD], s_cnt[NSHARD];
+    if (pass_voided(L)) return;
     TileMap m = tile_map(L);
     if (threadIdx.x < NSHARD) { s_incl[threadIdx.x] = m.incl; s_cnt[threadIdx.x] = m.cnt; }
     __syncthreads();
@@ -445,6 +454,7 @@ template <bool FUSED, bool RAYGEN, bool LDS_SCENE, bool BVH>
 __global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
+    if (pass_voided(L)) return;
     DevScene lsc = sc;  // what the shading step reads
     if (LDS_SCENE) {
         const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 4u * (sc.n_sph + sc.n_pl);
@@ -554,6 +564,7 @@ template <bool RAYGEN, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Level L, Level Lnext, PassParams pp, uint32_t level,
                                                                uint32_t last_traced, uint32_t *traced_count, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
+    if (pass_voided(L)) return;
     DevScene lsc = sc;  // what the shading step reads
     if (LDS_SCENE) {
         const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 4u * (sc.n_sph + sc.n_pl);
@@ -696,6 +707,7 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene
     __shared__ float4 s_a[BLOCK], s_b[BLOCK];
     __shared__ uint2 s_c[BLOCK];
     __shared__ uint32_t s_cnt[BLOCK / 64][8];
+    if (pass_voided(L)) return;
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -770,6 +782,7 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene
 // per-shard counters like Level::count (zeroed every pass, summed by k_account).
 template <bool BVH>
 __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, uint32_t *shadow_count) {
+    if (pass_voided(L)) return;
     TileMap m = tile_map(L);
     uint32_t n_shadow = 0;
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
@@ -801,6 +814,7 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
 // `pull`: level l + 1 is a traced level, so the children's radiance is taken from their records there (see
 // remember_children); otherwise (l is the last traced level) it is in the val slots, put there by k_terminal.
 __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lprev, uint32_t pull) {
+    if (pass_voided(L)) return;
     TileMap m = tile_map(L);
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;

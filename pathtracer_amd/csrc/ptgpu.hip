@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -33,7 +35,8 @@ struct Pipe {
     bool resolved_pending = false;
     std::vector<Level> levels;
     std::vector<std::pair<void *, size_t>> level_allocs;  // (block, bytes) of each queue level
-    uint32_t *d_counts = nullptr;      // [(n_levels + 1) * NSHARD * CSTRIDE]: per level, then the shadow-ray row
+    uint32_t *d_counts = nullptr;      // [(n_levels + 2) * NSHARD * CSTRIDE]: per level, then the shadow-ray row, then the traced row
+    uint32_t *d_shard_caps = nullptr;  // [n_levels] shard capacity of each level (the handle's array: all its pipes are sized alike)
     uint2 *d_bvh_spill = nullptr;
     DevScene sc{};                     // the handle's scene with this pipe's spill area
 };
@@ -54,6 +57,7 @@ struct PtHandle {
     float4 *d_bvh_geom = nullptr;
     uint32_t *d_bvh_always = nullptr;
     uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
+    uint64_t bvh_depth = 0, bvh_binary_depth = 0, bvh_forced_median_splits = 0, bvh_level_fold = 0;
     bool has_glass = false;
 
     // accumulators
@@ -62,7 +66,8 @@ struct PtHandle {
     uint8_t *h_pixels8 = nullptr;  // page-locked host copy handed out by ptgpu_present_pixels8 (sized for the current scene)
     uint32_t *d_ids = nullptr;
     uint64_t num_samples = 0;      // what pixels8 divides by (global count after a multi-GPU combine)
-    uint64_t local_samples = 0;    // samples per pixel this handle rendered since clear
+    uint64_t local_samples = 0;    // samples per pixel this handle accumulated since clear
+    uint64_t sample_cursor = 0;    // local index of the next sample to render: never reused, also not when a pass was dropped
 
     // queues: one set per pass in flight
     int n_levels = 0;              // max_depth + 1
@@ -110,6 +115,19 @@ int fail(PtHandle *h, int code, const std::string &msg) {
             return fail(h, e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP,                    \
                         std::string(#call) + ": " + hipGetErrorString(e_));                                  \
     } while (0)
+
+// No C++ exception may cross the C boundary (a std::bad_alloc from a scene-sized std::vector would reach a C, Rust or
+// ctypes caller as std::terminate): every entry point that returns a status runs between these two.
+int api_caught(PtHandle *h, int code, const char *what) noexcept {
+    try { if (h) h->error = what; } catch (...) { }
+    return code;
+}
+#define PT_API_BEGIN try {
+#define PT_API_END(h)                                                                                        \
+    } catch (const std::bad_alloc &) { return api_caught(h, PT_ERR_OUT_OF_MEMORY, "host memory allocation failed"); \
+    } catch (const std::length_error &) { return api_caught(h, PT_ERR_OUT_OF_MEMORY, "host container size limit exceeded"); \
+    } catch (const std::exception &e) { return api_caught(h, PT_ERR_INTERNAL, e.what());                     \
+    } catch (...) { return api_caught(h, PT_ERR_INTERNAL, "unknown C++ exception"); }
 
 template <class T>
 int dev_alloc(PtHandle *h, T **p, size_t n) {
@@ -198,6 +216,46 @@ void pack_plane(const PtPlane &p, float4 *out) {
     out[3] = make_float4(vn.z, vl, code_bits, 0.0f);
 }
 
+// Scene -> the flat tables the kernels read (ids: spheres, emissive spheres, planes, emissive planes; reference
+// src/scene.rs:266,280).
+void flatten_scene(const PtSceneDesc *s, std::vector<float4> &sph, std::vector<float4> &pln, std::vector<float4> &mat,
+                   std::vector<float4> &lights, bool &glass) {
+    // ---- flatten (ids: spheres, emissive spheres, planes, emissive planes; reference src/scene.rs:266,280)
+    const uint64_t n_sph = s->n_spheres + s->n_emissive_spheres, n_pl = s->n_planes + s->n_emissive_planes;
+    sph.assign(n_sph, float4{}); pln.assign(4 * n_pl, float4{}); mat.assign(4 * (n_sph + n_pl), float4{});
+    lights.assign(s->n_emissive_spheres + 4 * s->n_emissive_planes, float4{});
+    glass = false;
+    size_t id = 0;
+    auto put_sphere = [&](const PtSphere &sp) {
+        sph[id] = make_float4(sp.origin.x, sp.origin.y, sp.origin.z, sp.radius);
+        mat[4 * id] = mat0(sp.material); mat[4 * id + 1] = mat1(sp.material); mat[4 * id + 2] = mat2(sp.material); mat[4 * id + 3] = mat3(sp.material);
+        glass |= sp.material.kind == PT_MAT_TRANSLUCENT;
+        ++id;
+    };
+    for (uint64_t i = 0; i < s->n_spheres; ++i) put_sphere(s->spheres[i]);
+    for (uint64_t i = 0; i < s->n_emissive_spheres; ++i) {
+        const PtMaterial &m = s->emissive_spheres[i].material;
+        lights[i] = make_float4(m.color.x, m.color.y, m.color.z, 0.0f);
+        put_sphere(s->emissive_spheres[i]);
+    }
+    auto put_plane = [&](const PtPlane &p) {
+        pack_plane(p, &pln[4 * (id - n_sph)]);
+        mat[4 * id] = mat0(p.material); mat[4 * id + 1] = mat1(p.material); mat[4 * id + 2] = mat2(p.material); mat[4 * id + 3] = mat3(p.material);
+        glass |= p.material.kind == PT_MAT_TRANSLUCENT;
+        ++id;
+    };
+    for (uint64_t i = 0; i < s->n_planes; ++i) put_plane(s->planes[i]);
+    for (uint64_t i = 0; i < s->n_emissive_planes; ++i) {
+        const PtPlane &p = s->emissive_planes[i];
+        float4 *L = &lights[s->n_emissive_spheres + 4 * i];
+        L[0] = make_float4(p.origin.x, p.origin.y, p.origin.z, p.normal.x);
+        L[1] = make_float4(p.normal.y, p.normal.z, p.u.x, p.u.y);
+        L[2] = make_float4(p.u.z, p.v.x, p.v.y, p.v.z);
+        L[3] = make_float4(p.material.color.x, p.material.color.y, p.material.color.z, 0.0f);
+        put_plane(p);
+    }
+}
+
 hipEvent_t get_event(PtHandle *h) {
     if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -211,7 +269,7 @@ struct Span {
         if (h->cfg.profile_events) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
     }
     ~Span() {
-        if (h->cfg.profile_events) { (void)hipEventRecord(b, st); h->spans.push_back({k, a, b}); }
+        if (a) { (void)hipEventRecord(b, st); h->spans.push_back({k, a, b}); }
     }
 };
 
@@ -288,6 +346,7 @@ int alloc_levels(PtHandle *h) {
         if ((rc = dev_alloc(h, &pipe.d_counts, (size_t)(h->n_levels + 2) * NSHARD * CSTRIDE))) return rc;
         HIPCHK(h, hipMemsetAsync(pipe.d_counts, 0, (size_t)(h->n_levels + 2) * NSHARD * CSTRIDE * 4, h->stream));
         pipe.sc = h->sc;
+        pipe.d_shard_caps = h->d_shard_caps;
         if (h->sc.bvh_nodes) {
             if ((rc = dev_alloc(h, &pipe.d_bvh_spill, (size_t)(BVH_STACK - BVH_LDS_ENTRIES) * BVH_TRAV_BLOCKS * BVH_STACK_STRIDE))) return rc;
             pipe.sc.bvh_spill = pipe.d_bvh_spill;
@@ -339,7 +398,9 @@ static int grid_tiles(uint64_t level0_records) {
 }
 #define GRID_TILES grid_tiles(S)
 
-int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_first) {
+// Enqueues one pipeline pass on `pipe`: `spp` samples per pixel starting at local sample index `local_first`.  `flag` is the
+// pass's overflow word (device memory): cleared at the start of the pass, set by an append that finds a level full.
+int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_first, uint32_t *flag) {
     const uint32_t P = h->sc.width * h->sc.height;
     const DevScene &sc = pipe.sc;
     std::vector<Level> &levels = pipe.levels;
@@ -357,11 +418,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
     HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
-    // this pass's overflow flag: a slot of the ring, remembered until the host has looked at it
-    const uint32_t slot = (uint32_t)(h->flag_cursor++ % FLAG_RING);
-    uint32_t *flag = h->d_flags + slot;
     for (Level &L : levels) L.overflow = flag;
-    h->pending.push_back({slot, spp, local_first});
     k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap, flag);
     if (!h->fused && !h->ahead) {
         Span s(h, PT_KERNEL_RAYGEN, st);
@@ -433,10 +490,23 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         Span s(h, PT_KERNEL_RESOLVE, st);
         k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], levels[1], pp, spp, D >= 2 ? 1u : 0u, h->d_pixels32);
     }
-    k_account<<<1, 64, 0, st>>>(pipe.d_counts, h->d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
+    k_account<<<1, 64, 0, st>>>(pipe.d_counts, pipe.d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(pipe.resolved, st));
     pipe.resolved_pending = true;
+    return PT_OK;
+}
+
+// The next pass of the handle's own queues: round-robin over the pipes, its overflow flag a slot of the ring that is
+// remembered (with the samples it stands for) until the host has looked at it.
+int launch_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
+    Pipe &pipe = h->pipes[h->passes % h->n_pipes];
+    Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;  // the pass before this one
+    const uint32_t slot = (uint32_t)(h->flag_cursor++ % FLAG_RING);
+    h->pending.push_back({slot, spp, local_first});
+    int rc = run_pass(h, pipe, other, spp, local_first, h->d_flags + slot);
+    if (rc) return rc;
+    ++h->passes;
     return PT_OK;
 }
 
@@ -451,8 +521,15 @@ int sync_pipes(PtHandle *h) {
 // Looks at the overflow flags of the passes launched since the last look (all streams idle).  Voided passes are
 // repeated: with the levels re-allocated for twice the branching each time round, which ends at the latest when a
 // level can hold 2^level records per sample.  With a fixed PtConfig.branch_capacity an overflow is an error instead.
+struct Range { uint32_t first, spp; };
+void drop_voided(PtHandle *h, const std::vector<Range> &todo) {
+    uint64_t lost = 0;
+    for (const Range &r : todo) lost += r.spp;
+    h->local_samples -= std::min(h->local_samples, lost);
+    h->num_samples -= std::min(h->num_samples, lost);
+}
+
 int resolve_pending(PtHandle *h) {
-    struct Range { uint32_t first, spp; };
     std::vector<Range> todo;  // sample ranges (per pixel) still to be rendered again, served from the back
     for (;;) {
         // ---- look at the flags of everything launched since the last look
@@ -464,14 +541,25 @@ int resolve_pending(PtHandle *h) {
                 if (flags[p.slot]) { todo.push_back({p.first, p.spp}); any = true; }
             h->pending.clear();
             if (any) {
-                if (h->fixed_capacity)
+                if (h->fixed_capacity || h->growth >= (1u << 30)) {
+                    // the voided passes added nothing and are not repeated: take them out of the counts pixels8 and a
+                    // multi-GPU combine divide by (their sample indices stay used up)
+                    drop_voided(h, todo);
                     return fail(h, PT_ERR_QUEUE_OVERFLOW,
-                                "a ray queue level overflowed (glass branching beyond branch_capacity); the samples of that pass are missing");
-                if (h->growth >= (1u << 30)) return fail(h, PT_ERR_QUEUE_OVERFLOW, "a ray queue level overflowed at full capacity");
+                                h->fixed_capacity ? "a ray queue level overflowed (glass branching beyond branch_capacity); the samples of that pass are missing"
+                                                  : "a ray queue level overflowed at full capacity; the samples of that pass are missing");
+                }
                 h->growth *= 2;
                 free_levels(h);
                 int rc = alloc_levels(h);
-                if (rc) return rc;
+                if (rc) {
+                    // No usable queues any more (out of memory at the doubled size, or a level beyond 31-bit indices): the
+                    // handle goes back to "no scene" so that later calls fail with PT_ERR_NO_SCENE instead of launching
+                    // kernels on freed queues.  The error text says what happened.
+                    std::string why = h->error;
+                    free_scene(h);
+                    return fail(h, rc, "queues could not be re-allocated after an overflow (" + why + "); the scene has to be uploaded again");
+                }
             }
         }
         if (todo.empty()) return PT_OK;
@@ -479,11 +567,8 @@ int resolve_pending(PtHandle *h) {
         while (!todo.empty() && h->pending.size() + PT_MAX_PIPES < FLAG_RING) {
             Range &r = todo.back();
             const uint32_t spp = std::min(h->batch, r.spp);  // (the pass size may have shrunk with the new level sizes)
-            Pipe &pipe = h->pipes[h->passes % h->n_pipes];
-            Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;
-            int rc = run_pass(h, pipe, other, spp, r.first);
-            if (rc) return rc;
-            ++h->passes;
+            int rc = launch_pass(h, spp, r.first);
+            if (rc) { drop_voided(h, todo); return rc; }
             r.first += spp;
             r.spp -= spp;
             if (r.spp == 0) todo.pop_back();
@@ -518,6 +603,7 @@ void ptgpu_default_config(PtConfig *cfg) {
 }
 
 int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
+    PT_API_BEGIN
     if (!cfg || !out) return PT_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (cfg->max_depth < 1 || cfg->max_depth > 24 || cfg->shard_count == 0 || cfg->shard_index >= cfg->shard_count)
@@ -540,6 +626,7 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
     if (!ok) { ptgpu_destroy(h); return PT_ERR_HIP; }
     *out = h;
     return PT_OK;
+    PT_API_END(nullptr)
 }
 
 void ptgpu_destroy(PtHandle *h) {
@@ -557,6 +644,7 @@ void ptgpu_destroy(PtHandle *h) {
 }
 
 int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
+    PT_API_BEGIN
     if (!h || !s) return PT_ERR_INVALID_ARGUMENT;
     if (s->width == 0 || s->height == 0 || (uint64_t)s->width * s->height > (1ull << 28))
         return fail(h, PT_ERR_INVALID_ARGUMENT, "image size must be 1..2^28 pixels");
@@ -566,41 +654,13 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     const uint64_t n_sph = s->n_spheres + s->n_emissive_spheres, n_pl = s->n_planes + s->n_emissive_planes;
     if (n_sph + n_pl >= (1ull << 28)) return fail(h, PT_ERR_INVALID_ARGUMENT, "too many primitives");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // every pipe, not only the handle's stream: a render call that failed midway never joined the others into it
+    for (Pipe &p : h->pipes) if (p.stream) HIPCHK(h, hipStreamSynchronize(p.stream));
     free_scene(h);
 
-    // ---- flatten (ids: spheres, emissive spheres, planes, emissive planes; reference src/scene.rs:266,280)
-    std::vector<float4> sph(n_sph), pln(4 * n_pl), mat(4 * (n_sph + n_pl)), lights(s->n_emissive_spheres + 4 * s->n_emissive_planes);
+    std::vector<float4> sph, pln, mat, lights;
     bool glass = false;
-    size_t id = 0;
-    auto put_sphere = [&](const PtSphere &sp) {
-        sph[id] = make_float4(sp.origin.x, sp.origin.y, sp.origin.z, sp.radius);
-        mat[4 * id] = mat0(sp.material); mat[4 * id + 1] = mat1(sp.material); mat[4 * id + 2] = mat2(sp.material); mat[4 * id + 3] = mat3(sp.material);
-        glass |= sp.material.kind == PT_MAT_TRANSLUCENT;
-        ++id;
-    };
-    for (uint64_t i = 0; i < s->n_spheres; ++i) put_sphere(s->spheres[i]);
-    for (uint64_t i = 0; i < s->n_emissive_spheres; ++i) {
-        const PtMaterial &m = s->emissive_spheres[i].material;
-        lights[i] = make_float4(m.color.x, m.color.y, m.color.z, 0.0f);
-        put_sphere(s->emissive_spheres[i]);
-    }
-    auto put_plane = [&](const PtPlane &p) {
-        pack_plane(p, &pln[4 * (id - n_sph)]);
-        mat[4 * id] = mat0(p.material); mat[4 * id + 1] = mat1(p.material); mat[4 * id + 2] = mat2(p.material); mat[4 * id + 3] = mat3(p.material);
-        glass |= p.material.kind == PT_MAT_TRANSLUCENT;
-        ++id;
-    };
-    for (uint64_t i = 0; i < s->n_planes; ++i) put_plane(s->planes[i]);
-    for (uint64_t i = 0; i < s->n_emissive_planes; ++i) {
-        const PtPlane &p = s->emissive_planes[i];
-        float4 *L = &lights[s->n_emissive_spheres + 4 * i];
-        L[0] = make_float4(p.origin.x, p.origin.y, p.origin.z, p.normal.x);
-        L[1] = make_float4(p.normal.y, p.normal.z, p.u.x, p.u.y);
-        L[2] = make_float4(p.u.z, p.v.x, p.v.y, p.v.z);
-        L[3] = make_float4(p.material.color.x, p.material.color.y, p.material.color.z, 0.0f);
-        put_plane(p);
-    }
+    flatten_scene(s, sph, pln, mat, lights, glass);
     h->has_glass = glass;
 
     int rc;
@@ -665,6 +725,7 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     // 27 primitives 21.8 vs 7.6 Grays/s, 87: 11.6 vs 6.9, 167: 7.4 vs 6.4.
     bool want_bvh = h->cfg.accel == PT_ACCEL_BVH || (h->cfg.accel == PT_ACCEL_AUTO && n_sph + n_pl > 192);
     h->bvh_nodes = h->bvh_leaf_prims = 0;
+    h->bvh_depth = h->bvh_binary_depth = h->bvh_forced_median_splits = h->bvh_level_fold = 0;
     h->lds_bytes = 0;
     if (want_bvh && n_sph + n_pl > 0) {
         BvhBuilder builder;
@@ -680,6 +741,8 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
         sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_geom = h->d_bvh_geom;  // (the spill area belongs to the pipes)
         sc.bvh_always = h->d_bvh_always; sc.n_always = (uint32_t)builder.always.size();
         h->bvh_nodes = builder.nodes.size(); h->bvh_leaf_prims = builder.prims.size();
+        h->bvh_depth = (uint64_t)builder.depth4; h->bvh_binary_depth = (uint64_t)builder.max_depth_seen;
+        h->bvh_forced_median_splits = builder.forced_median_splits; h->bvh_level_fold = builder.level_fold ? 1 : 0;
         h->lds_bytes = (size_t)BVH_LDS_ENTRIES * BVH_STACK_STRIDE * sizeof(uint2);
     }
     // auto: BVH scenes run intersection as its own kernel (dynamic ray fetch), small scenes fuse it with shading
@@ -703,9 +766,11 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     if ((rc = alloc_levels(h))) return rc;
     h->have_scene = true;
     return ptgpu_clear(h);
+    PT_API_END(h)
 }
 
 int ptgpu_clear(PtHandle *h) {
+    PT_API_BEGIN
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
@@ -721,12 +786,15 @@ int ptgpu_clear(PtHandle *h) {
     if (rc) return rc;
     h->num_samples = 0;
     h->local_samples = 0;
+    h->sample_cursor = 0;
     std::memset(h->kernel_launches, 0, sizeof h->kernel_launches);
     std::memset(h->kernel_ms, 0, sizeof h->kernel_ms);
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_render(PtHandle *h, uint32_t n_samples) {
+    PT_API_BEGIN
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
@@ -735,12 +803,10 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
     uint32_t done = 0;
     while (done < n_samples) {
         uint32_t spp = std::min(h->batch, n_samples - done);
-        Pipe &pipe = h->pipes[h->passes % h->n_pipes];
-        Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;  // the pass before this one
-        int rc = run_pass(h, pipe, other, spp, (uint32_t)h->local_samples);
+        int rc = launch_pass(h, spp, (uint32_t)h->sample_cursor);
         if (rc) return rc;
-        ++h->passes;
         done += spp;
+        h->sample_cursor += spp;
         h->local_samples += spp;
         h->num_samples += spp;
         if (h->pending.size() + PT_MAX_PIPES >= FLAG_RING) {  // every flag slot is in use: look at them now
@@ -756,9 +822,11 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
     for (int q = 1; q < h->n_pipes; ++q)
         if (h->pipes[q].resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->pipes[q].resolved, 0));
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_sync(PtHandle *h) {
+    PT_API_BEGIN
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->device));
     int rc0 = sync_pipes(h);
@@ -767,9 +835,11 @@ int ptgpu_sync(PtHandle *h) {
     if (rc) return rc;
     if (h->have_scene) return resolve_pending(h);
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_read_pixels32(PtHandle *h, uint32_t *out, uint64_t *num_samples) {
+    PT_API_BEGIN
     if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     int rc = ptgpu_sync(h);
@@ -778,9 +848,11 @@ int ptgpu_read_pixels32(PtHandle *h, uint32_t *out, uint64_t *num_samples) {
     HIPCHK(h, hipMemcpy(out, h->d_pixels32, P * 3 * 4, hipMemcpyDeviceToHost));
     if (num_samples) *num_samples = h->num_samples;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_read_pixels8(PtHandle *h, uint8_t *out) {
+    PT_API_BEGIN
     if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     int rc = ptgpu_sync(h);
@@ -792,9 +864,11 @@ int ptgpu_read_pixels8(PtHandle *h, uint8_t *out) {
     HIPCHK(h, hipMemcpyAsync(out, h->d_pixels8, n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_present_pixels8(PtHandle *h, const uint8_t **pixels) {
+    PT_API_BEGIN
     if (!h || !pixels) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     const uint32_t n = h->sc.width * h->sc.height * 3;
@@ -803,9 +877,11 @@ int ptgpu_present_pixels8(PtHandle *h, const uint8_t **pixels) {
     if (rc) return rc;
     *pixels = h->h_pixels8;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out) {
+    PT_API_BEGIN
     if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
@@ -817,9 +893,11 @@ int ptgpu_render_primary_ids(PtHandle *h, uint32_t sample_index, uint32_t *out) 
     HIPCHK(h, hipMemcpyAsync(out, h->d_ids, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_device_pixels32(PtHandle *h, void **device_ptr, uint64_t *n_words) {
+    PT_API_BEGIN
     if (!h || !device_ptr) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     int rc = ptgpu_sync(h);
@@ -827,15 +905,19 @@ int ptgpu_device_pixels32(PtHandle *h, void **device_ptr, uint64_t *n_words) {
     *device_ptr = h->d_pixels32;
     if (n_words) *n_words = (uint64_t)h->sc.width * h->sc.height * 3;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_set_num_samples(PtHandle *h, uint64_t num_samples) {
+    PT_API_BEGIN
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     h->num_samples = num_samples;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_export_pixels32(PtHandle *h, void *dst_device) {
+    PT_API_BEGIN
     if (!h || !dst_device) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     int rc = ptgpu_sync(h);
@@ -844,26 +926,33 @@ int ptgpu_export_pixels32(PtHandle *h, void *dst_device) {
     HIPCHK(h, hipMemcpyAsync(dst_device, h->d_pixels32, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_import_pixels32(PtHandle *h, const void *src_device, uint64_t num_samples) {
+    PT_API_BEGIN
     if (!h || !src_device) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
-    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ptgpu_sync(h);  // passes still in flight (and repeats of voided ones) add into the accumulator this call replaces
+    if (rc) return rc;
     const size_t bytes = (size_t)h->sc.width * h->sc.height * 3 * 4;
     HIPCHK(h, hipMemcpyAsync(h->d_pixels32, src_device, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->num_samples = num_samples;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_stream(PtHandle *h, void **stream) {
+    PT_API_BEGIN
     if (!h || !stream) return PT_ERR_INVALID_ARGUMENT;
     *stream = (void *)h->stream;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_get_stats(PtHandle *h, PtStats *out) {
+    PT_API_BEGIN
     if (!h || !out) return PT_ERR_INVALID_ARGUMENT;
     std::memset(out, 0, sizeof *out);
     if (h->have_scene) {
@@ -882,9 +971,38 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
     }
     out->bvh_nodes = h->bvh_nodes;
     out->bvh_leaf_prims = h->bvh_leaf_prims;
+    out->bvh_depth = h->bvh_depth;
+    out->bvh_binary_depth = h->bvh_binary_depth;
+    out->bvh_forced_median_splits = h->bvh_forced_median_splits;
+    out->bvh_level_fold = h->bvh_level_fold;
+    out->queue_bytes = h->level_bytes;
     for (int k = 0; k < PT_KERNEL_COUNT; ++k) { out->kernel_launches[k] = h->kernel_launches[k]; out->kernel_ms[k] = h->kernel_ms[k]; }
     out->device_bytes = h->device_bytes;
     return PT_OK;
+    PT_API_END(h)
+}
+
+int ptgpu_bvh_build_stats(const PtSceneDesc *s, PtStats *out) {
+    PT_API_BEGIN
+    if (!s || !out) return PT_ERR_INVALID_ARGUMENT;
+    if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_emissive_spheres && !s->emissive_spheres) ||
+        (s->n_emissive_planes && !s->emissive_planes))
+        return PT_ERR_INVALID_ARGUMENT;
+    if (s->n_spheres + s->n_emissive_spheres + s->n_planes + s->n_emissive_planes >= (1ull << 28)) return PT_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof *out);
+    std::vector<float4> sph, pln, mat, lights;
+    bool glass = false;
+    flatten_scene(s, sph, pln, mat, lights, glass);
+    BvhBuilder builder;
+    builder.build(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
+    out->bvh_nodes = builder.nodes.size();
+    out->bvh_leaf_prims = builder.prims.size();
+    out->bvh_depth = (uint64_t)builder.depth4;
+    out->bvh_binary_depth = (uint64_t)builder.max_depth_seen;
+    out->bvh_forced_median_splits = builder.forced_median_splits;
+    out->bvh_level_fold = builder.level_fold ? 1 : 0;
+    return PT_OK;
+    PT_API_END(nullptr)
 }
 
 const char *ptgpu_last_error(PtHandle *h) { return h ? h->error.c_str() : "null handle"; }
@@ -922,6 +1040,7 @@ void ptgpu_plane_normals(PtPlane *planes, uint64_t n) {
 }
 
 int ptgpu_selftest_gamma(PtHandle *h, uint64_t *mismatches) {
+    PT_API_BEGIN
     if (!h || !mismatches) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
@@ -940,9 +1059,11 @@ int ptgpu_selftest_gamma(PtHandle *h, uint64_t *mismatches) {
     if (e != hipSuccess) return fail(h, PT_ERR_HIP, hipGetErrorString(e));
     *mismatches = host;
     return PT_OK;
+    PT_API_END(h)
 }
 
 int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n) {
+    PT_API_BEGIN
     if (!h || !a || !out || fn < 0 || fn > 8) return PT_ERR_INVALID_ARGUMENT;
     if (n == 0) return PT_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -960,6 +1081,7 @@ int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, flo
     (void)hipFree(da); (void)hipFree(dout); (void)hipFree(db);   // (hipFree(nullptr) is a no-op)
     if (e != hipSuccess) return fail(h, PT_ERR_HIP, hipGetErrorString(e));
     return PT_OK;
+    PT_API_END(h)
 }
 
 }  // extern "C"

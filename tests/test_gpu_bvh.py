@@ -141,3 +141,96 @@ def test_rays_parallel_to_an_axis(binding, oracle):
     assert np.array_equal(ids, ref)
     r32, _, _ = osc.render(oracle.options(sub_pixel_override=0), 2)
     assert np.array_equal(p32, r32)
+
+
+# ---- the ~1M-primitive procedural scene at its full size ------------------------------------------------------------
+# The oracle needs ~27 ms per ray here (it scans a million primitives the way find_scene_hit does), so it checks small
+# images of the same camera; the GPU's own linear scan, itself oracle-checked everywhere else, covers the larger ones.
+def _full_field(width, height):
+    return S.quad_field_scene(width, height, grid=1000, n_spheres=1000)
+
+
+def test_full_field_bvh_shape(binding):
+    with binding.PtGpu(accel=binding.ACCEL_AUTO) as gpu:
+        gpu.upload_scene(_full_field(64, 36))
+        st = gpu.stats()
+    assert st["bvh_leaf_prims"] == 1_001_001
+    assert 480_000 < st["bvh_nodes"] < 560_000       # 4-wide nodes over a binary tree of 1M leaves
+    # the field is regular enough that binned SAH stays balanced: no forced median split, folded by box area
+    assert st["bvh_binary_depth"] <= 30 and st["bvh_forced_median_splits"] == 0 and st["bvh_level_fold"] == 0
+    assert 3 * st["bvh_depth"] <= 64                 # the traversal stack's bound
+
+
+def test_full_field_primary_ids_bvh_equals_gpu_linear_scan(binding):
+    sc = _full_field(256, 144)
+    with binding.PtGpu(accel=binding.ACCEL_BVH) as gpu:
+        gpu.upload_scene(sc)
+        ids_b = [gpu.primary_ids(s) for s in range(2)]
+    with binding.PtGpu(accel=binding.ACCEL_BRUTE_FORCE) as gpu:
+        gpu.upload_scene(sc)
+        ids_l = [gpu.primary_ids(s) for s in range(2)]
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    hit = ids_b[0] != 0xFFFFFFFF
+    assert hit.mean() > 0.4 and len(np.unique(ids_b[0])) > 5000
+
+
+def test_full_field_pixels_bvh_equals_gpu_linear_scan(binding):
+    sc = _full_field(64, 36)
+    _, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 1)
+    _, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 1)
+    assert np.array_equal(p_b, p_l)
+    # (no shadow rays here: the overhead light faces down, so Plane::sample says None for every point below it,
+    #  reference src/scene.rs:117)
+    assert st_b["rays"] == st_l["rays"] > 64 * 36 and st_b["records"] == st_l["records"]
+
+
+def test_full_field_against_oracle(binding, oracle):
+    sc = _full_field(40, 22)
+    with binding.PtGpu(accel=binding.ACCEL_BVH) as gpu:
+        gpu.upload_scene(sc)
+        ids = gpu.primary_ids(0)
+    assert np.array_equal(ids, oracle.OracleScene(sc).primary_ids(oracle.options(), 0))
+    small = _full_field(24, 14)
+    _, p_b, st_b = _ids_and_pixels(binding, small, binding.ACCEL_BVH, 1)
+    r32, _, rays = oracle.OracleScene(small).render(oracle.options(), 1)   # bounce and shadow rays through the BVH too
+    assert np.array_equal(p_b, r32) and st_b["rays"] == rays
+
+
+# ---- a tree as deep as the builder allows ------------------------------------------------------------------------------
+def skewed_spheres_scene(n=300, width=48, height=36):
+    """Spheres on the x axis whose positions and radii grow geometrically over 36 decades: binned SAH peels a few of
+    the largest off at every split, so the binary tree is a spine that runs into the builder's depth cap (forced median
+    splits) and, folded by box area, a 4-wide tree far deeper than the traversal stack could follow.  The camera looks
+    along the row from beside it: its rays pierce most boxes (all of them once the boxes are padded for 1e18-sized
+    coordinates) and miss most spheres."""
+    ratio = 1e36 ** (1.0 / n)
+    x = 1e-18 * ratio ** np.arange(n)
+    sc = S.Scene(image_settings=S.ImageSettings(width, height, True),
+                 camera=S.Camera((-1.0, 0.45, 0.0), (1.0, 0.9, 0.0), (0.0, 1.0, 0.0), 0.4, 0.3, 0.5, S.TONE_CLAMP, 1.0, 100.0),
+                 sky=S.Sky.constant((0.6, 0.7, 0.8)))
+    sp = np.zeros(n, dtype=S.SPHERE_DT)
+    sp["radius"] = (0.3 * x).astype(np.float32)
+    sp["origin"] = np.stack([x, np.zeros(n), np.zeros(n)], axis=1).astype(np.float32)
+    sp["material"]["kind"] = S.MAT_PHYSICALLY
+    sp["material"]["color"] = (0.8, 0.5, 0.3)
+    sp["material"]["roughness"] = 0.6
+    sp["material"]["ior"] = 1.0
+    sc.spheres = sp
+    sc.add(S.Plane((-4.0, 6.0, -4.0), (8.0, 0.0, 0.0), (0.0, 0.0, 8.0), S.Material.emissive((9.0, 9.0, 9.0))))
+    return sc
+
+
+def test_skewed_tree_is_refolded_and_traversed_exactly(binding, oracle):
+    sc = skewed_spheres_scene()
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 3, samples_per_batch=1, concurrent_passes=2)
+    assert st_b["bvh_binary_depth"] == 38 and st_b["bvh_forced_median_splits"] > 0
+    assert st_b["bvh_level_fold"] == 1 and 3 * st_b["bvh_depth"] <= 64
+    ids_l, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 3)
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_b, p_l) and st_b["rays"] == st_l["rays"]
+    osc = oracle.OracleScene(sc)
+    assert np.array_equal(ids_b[0], osc.primary_ids(oracle.options(), 0))
+    assert np.array_equal(p_b, osc.render(oracle.options(), 3)[0])
+    assert len(np.unique(ids_b[0])) > 5   # spheres of several sizes, the light or the sky are seen
