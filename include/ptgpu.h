@@ -163,6 +163,21 @@ int ptgpu_clear(PtHandle *h);
 int ptgpu_render(PtHandle *h, uint32_t n_samples);
 int ptgpu_sync(PtHandle *h);
 
+/* ptgpu_render for callers that cannot allocate.  No counterpart in the reference: it exists for hosts that must not
+ * call hipMalloc while they render - code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Same inputs (the uploaded scene) and outputs (the handle's accumulators, the same sample indices ptgpu_render would
+ * use next) and the same sums bit for bit, but the ray queues of its passes live in a fixed array of
+ * PTGPU_NOALLOC_SCRATCH_BYTES that is part of the loaded library (each GPU the library has run on holds one until the
+ * process ends) instead of in memory the handle allocated, and the call makes no hipMalloc/hipFree and no host
+ * allocation.  It returns when its samples are accumulated.
+ * Limits: the queues of ONE sample per pixel must fit the array - about 60 000 pixels for a scene with glass at
+ * max_depth 4, 110 000 without - else PT_ERR_INVALID_ARGUMENT; scenes traced through a BVH are refused likewise.  Glass
+ * that branches beyond what fits gives PT_ERR_QUEUE_OVERFLOW (the samples that did fit are kept and counted).
+ * All handles on one GPU share that GPU's array: calls that overlap on one GPU race; calls one after the other are
+ * safe (the call clears the counters it uses). */
+#define PTGPU_NOALLOC_SCRATCH_BYTES (64u << 20)
+int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples);
+
 /* Backbuffer.pixels32 (u32 x3 sums, row-major, row 0 = bottom) and the number of samples summed. */
 int ptgpu_read_pixels32(PtHandle *h, uint32_t *out, uint64_t *num_samples);
 /* Backbuffer.pixels8 exactly as assign_pixel8_unsafe leaves it after the last frame

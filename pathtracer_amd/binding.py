@@ -91,6 +91,7 @@ def load_library() -> C.CDLL:
     lib.ptgpu_clear.argtypes = [H]
     lib.ptgpu_render.argtypes = [H, C.c_uint32]
     lib.ptgpu_sync.argtypes = [H]
+    lib.ptgpu_render_noalloc.argtypes = [H, C.c_uint32]
     lib.ptgpu_read_pixels32.argtypes = [H, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.ptgpu_read_pixels8.argtypes = [H, C.c_void_p]
     lib.ptgpu_present_pixels8.argtypes = [H, C.POINTER(C.c_void_p)]
@@ -117,7 +118,7 @@ def load_library() -> C.CDLL:
     for name in ("ptgpu_create", "ptgpu_upload_scene", "ptgpu_clear", "ptgpu_render", "ptgpu_sync", "ptgpu_read_pixels32",
                  "ptgpu_read_pixels8", "ptgpu_render_primary_ids", "ptgpu_device_pixels32", "ptgpu_set_num_samples",
                  "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32", "ptgpu_selftest_gamma",
-                 "ptgpu_present_pixels8"):
+                 "ptgpu_present_pixels8", "ptgpu_render_noalloc"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -243,6 +244,10 @@ class PtGpu:
 
     def render(self, n_samples: int) -> None:
         self._chk(self.lib.ptgpu_render(self.h, int(n_samples)))
+
+    def render_noalloc(self, n_samples: int) -> None:
+        """ptgpu_render with its ray queues in the library's static device array: no allocation during the call."""
+        self._chk(self.lib.ptgpu_render_noalloc(self.h, int(n_samples)))
 
     def sync(self) -> None:
         self._chk(self.lib.ptgpu_sync(self.h))

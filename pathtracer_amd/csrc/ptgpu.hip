@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -24,6 +25,14 @@ namespace {
 struct EventSpan { int kernel; hipEvent_t start, stop; };
 
 }  // namespace
+
+// Queue memory of ptgpu_render_noalloc: the levels, counters and overflow flags of one pipeline pass, in an array that
+// is part of the loaded code object instead of coming from hipMalloc.  Every GPU the library runs on holds its own copy
+// at its own address (looked up once per device in ptgpu_create, with that device current); in host code the array's
+// name is only a handle for that lookup, never an address to pass to a kernel.
+static __device__ __align__(256) unsigned char scratch[PTGPU_NOALLOC_SCRATCH_BYTES];
+constexpr int PT_MAX_DEVICES = 64;
+constexpr uint32_t NOALLOC_FLAGS = 64;   // overflow flags (= passes) per round of ptgpu_render_noalloc
 
 // What one pipeline pass owns: its queues, counters, stream and (BVH scenes) traversal spill area.  Passes on
 // different pipes overlap on the GPU; only the accumulation into the pixel sums is ordered between them.
@@ -75,6 +84,9 @@ struct PtHandle {
     int n_pipes = 0;
     uint64_t passes = 0;           // passes launched since the scene was uploaded (pass k runs on pipe k % n_pipes)
     Pipe pipes[PT_MAX_PIPES];
+    unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
+    Pipe static_pipe;                      // ptgpu_render_noalloc's pass: queues carved out of scratch_ptr, the handle's stream
+    bool no_spans = false;                 // inside ptgpu_render_noalloc: no per-kernel events (creating one allocates)
     uint32_t *d_shard_caps = nullptr;  // [n_levels]
     Counters *d_ctr = nullptr;
     // Levels of a scene with glass are sized for `growth`-fold branching, not for the worst case 2^depth.  Every pass
@@ -266,7 +278,7 @@ hipEvent_t get_event(PtHandle *h) {
 struct Span {
     PtHandle *h; int k; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Span(PtHandle *h_, int k_, hipStream_t st_) : h(h_), k(k_), st(st_) {
-        if (h->cfg.profile_events) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
+        if (h->cfg.profile_events && !h->no_spans) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
     }
     ~Span() {
         if (a) { (void)hipEventRecord(b, st); h->spans.push_back({k, a, b}); }
@@ -578,6 +590,38 @@ int resolve_pending(PtHandle *h) {
     }
 }
 
+// ---- ptgpu_render without any allocation -------------------------------------------------------------------------
+// Where the pieces of one pass live inside the scratch array for a given pass size.
+struct ScratchPlan {
+    uint32_t caps[25];
+    size_t level_off[25];
+    size_t flags_off, caps_off, counts_off, end;
+};
+bool plan_scratch(uint64_t pixels, int n_levels, bool glass, uint32_t growth, uint32_t spp, ScratchPlan &pl) {
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    pl.flags_off = off; off = align(off + NOALLOC_FLAGS * 4);
+    pl.caps_off = off; off = align(off + 25 * 4);
+    pl.counts_off = off; off = align(off + (size_t)(n_levels + 2) * NSHARD * CSTRIDE * 4);
+    const uint64_t S = pixels * spp;
+    for (int l = 0; l < n_levels; ++l) {
+        const uint64_t f = glass ? std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), growth) : 1;
+        const uint64_t recs = S * f, per = (recs + NSHARD - 1) / NSHARD;
+        const uint64_t cap = l == 0 ? ((per + 63) / 64) * 64 : ((per + per / 4 + 128 + 63) / 64) * 64;   // as alloc_levels sizes them
+        if (cap * NSHARD >= (1ull << 31)) return false;
+        pl.caps[l] = (uint32_t)cap;
+        pl.level_off[l] = off;
+        off = align(off + (size_t)cap * NSHARD * Level::RECORD_BYTES);
+        if (off > (size_t)PTGPU_NOALLOC_SCRATCH_BYTES) return false;
+    }
+    pl.end = off;
+    return true;
+}
+struct CapsArg { uint32_t v[25]; };
+__global__ void k_set_caps(uint32_t *caps, CapsArg a, int n) {
+    if ((int)threadIdx.x < n) caps[threadIdx.x] = a.v[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" {
@@ -623,7 +667,26 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
     bool ok = true;
     for (int q = 1; q < PT_MAX_PIPES; ++q) ok = ok && hipStreamCreateWithFlags(&h->pipes[q].stream, hipStreamNonBlocking) == hipSuccess;
     for (Pipe &p : h->pipes) ok = ok && hipEventCreateWithFlags(&p.resolved, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->static_pipe.resolved, hipEventDisableTiming) == hipSuccess;
     if (!ok) { ptgpu_destroy(h); return PT_ERR_HIP; }
+    // this device's copy of the static scratch array (device cfg->device is current)
+    if (cfg->device < PT_MAX_DEVICES) {
+        static std::mutex table_lock;
+        static unsigned char *table[PT_MAX_DEVICES] = {};
+        std::lock_guard<std::mutex> guard(table_lock);
+        if (!table[cfg->device]) {
+            unsigned char *ptr = nullptr;
+            if (hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) {
+                (void)hipGetLastError();
+                ptgpu_destroy(h);
+                return PT_ERR_HIP;
+            }
+            table[cfg->device] = ptr;
+        }
+        h->scratch_ptr = table[cfg->device];
+    }
+    h->static_pipe.stream = h->stream;
+    h->static_pipe.levels.resize(25);   // max_depth <= 24: sized here so that ptgpu_render_noalloc never allocates on the host either
     *out = h;
     return PT_OK;
     PT_API_END(nullptr)
@@ -636,6 +699,7 @@ void ptgpu_destroy(PtHandle *h) {
     free_scene(h);
     drain_level_pool(h);
     for (Pipe &p : h->pipes) if (p.resolved) (void)hipEventDestroy(p.resolved);
+    if (h->static_pipe.resolved) (void)hipEventDestroy(h->static_pipe.resolved);
     for (int q = 1; q < PT_MAX_PIPES; ++q) if (h->pipes[q].stream) (void)hipStreamDestroy(h->pipes[q].stream);
     for (auto &s : h->spans) { (void)hipEventDestroy(s.start); (void)hipEventDestroy(s.stop); }
     for (auto e : h->free_events) (void)hipEventDestroy(e);
@@ -823,6 +887,111 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
         if (h->pipes[q].resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->pipes[q].resolved, 0));
     return PT_OK;
     PT_API_END(h)
+}
+
+int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
+    if (!h) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return api_caught(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (!h->scratch_ptr) return api_caught(h, PT_ERR_INVALID_ARGUMENT, "ptgpu_render_noalloc: no static scratch on this device ordinal");
+    if (h->sc.bvh_nodes)
+        return api_caught(h, PT_ERR_INVALID_ARGUMENT,
+                          "ptgpu_render_noalloc: scenes traced through a BVH (more than 192 primitives, or PT_ACCEL_BVH) need a "
+                          "traversal spill area larger than the static scratch; use ptgpu_render");
+    if (n_samples == 0) return PT_OK;
+    // Errors below are reported through fixed strings (api_caught): building a message would allocate.
+#define NA_HIP(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); h->no_spans = false; return api_caught(h, PT_ERR_HIP, "ptgpu_render_noalloc: " #call " failed"); } } while (0)
+    NA_HIP(hipSetDevice(h->device));
+    // passes of earlier ptgpu_render calls add into the same accumulator from other streams: let them finish (their
+    // overflow flags stay pending for the next ptgpu_sync)
+    for (Pipe &p : h->pipes) if (p.stream) NA_HIP(hipStreamSynchronize(p.stream));
+    const uint64_t P = (uint64_t)h->sc.width * h->sc.height;
+    const int n_levels = h->cfg.max_depth + 1;
+    uint32_t growth = h->fixed_capacity ? h->cfg.branch_capacity : 2u;
+    ScratchPlan pl;
+    auto largest_pass = [&](uint32_t want) -> uint32_t {   // most samples per pass (<= want) whose queues fit the scratch; 0: not even one
+        uint32_t spp = std::min<uint32_t>(want, 64);
+        while (spp > 0 && !plan_scratch(P, n_levels, h->has_glass, growth, spp, pl)) spp /= 2;
+        return spp;
+    };
+    uint32_t spp = largest_pass(n_samples);
+    if (spp == 0)
+        return api_caught(h, PT_ERR_INVALID_ARGUMENT,
+                          "ptgpu_render_noalloc: the ray queues of one sample per pixel of this image at this max_depth exceed the "
+                          "static scratch (PTGPU_NOALLOC_SCRATCH_BYTES); use ptgpu_render or a smaller image");
+    Pipe &pipe = h->static_pipe;
+    pipe.sc = h->sc;
+    h->no_spans = true;
+    struct Range { uint32_t first, count; };
+    constexpr int STACK = 512;
+    Range stack[STACK];
+    int sp = 0;
+    stack[sp++] = {(uint32_t)h->sample_cursor, n_samples};
+    h->sample_cursor += n_samples;
+    bool planned = false;
+    uint64_t lost = 0;   // samples of passes that overflowed and could not be repeated
+    while (sp > 0) {
+        if (!planned) {   // (re)carve the scratch for the current growth and pass size
+            unsigned char *base = h->scratch_ptr;
+            pipe.d_counts = (uint32_t *)(base + pl.counts_off);
+            pipe.d_shard_caps = (uint32_t *)(base + pl.caps_off);
+            CapsArg caps{};
+            for (int l = 0; l < n_levels; ++l) {
+                Level &L = pipe.levels[l];
+                L.base = (char *)(base + pl.level_off[l]);
+                L.count = pipe.d_counts + (size_t)l * NSHARD * CSTRIDE;
+                L.shard_cap = pl.caps[l];
+                caps.v[l] = pl.caps[l];
+            }
+            // the array keeps whatever the last call on this GPU left in it: counters start at zero
+            NA_HIP(hipMemsetAsync(base, 0, pl.level_off[0], h->stream));
+            k_set_caps<<<1, 32, 0, h->stream>>>(pipe.d_shard_caps, caps, n_levels);
+            planned = true;
+        }
+        Range r = stack[--sp];
+        // one round: up to NOALLOC_FLAGS passes of this range, each with its own overflow flag
+        Range launched[NOALLOC_FLAGS];
+        uint32_t n_launched = 0;
+        while (r.count > 0 && n_launched < NOALLOC_FLAGS) {
+            const uint32_t k = std::min(spp, r.count);
+            uint32_t *flag = (uint32_t *)(h->scratch_ptr + pl.flags_off) + n_launched;
+            int rc = run_pass(h, pipe, nullptr, k, r.first, flag);
+            if (rc) { h->no_spans = false; return rc; }
+            launched[n_launched++] = {r.first, k};
+            r.first += k;
+            r.count -= k;
+        }
+        if (r.count > 0) stack[sp++] = r;
+        uint32_t flags[NOALLOC_FLAGS];
+        NA_HIP(hipStreamSynchronize(h->stream));
+        NA_HIP(hipMemcpy(flags, h->scratch_ptr + pl.flags_off, n_launched * 4, hipMemcpyDeviceToHost));
+        bool any = false;
+        for (uint32_t k = 0; k < n_launched; ++k) {
+            if (!flags[k]) { h->local_samples += launched[k].count; h->num_samples += launched[k].count; continue; }
+            any = true;
+            if (sp < STACK) stack[sp++] = launched[k]; else lost += launched[k].count;
+        }
+        if (any) {   // glass branched beyond the levels: the voided passes are on the stack again; make room for twice the branching
+            uint32_t next_spp = 0;
+            if (!h->fixed_capacity && growth < (1u << 30)) {
+                growth *= 2;
+                next_spp = largest_pass(spp);
+            }
+            if (next_spp == 0) {   // cannot grow inside the scratch: everything still to do is dropped
+                for (int k = 0; k < sp; ++k) lost += stack[k].count;
+                sp = 0;
+                break;
+            }
+            spp = next_spp;
+            planned = false;
+        }
+    }
+    h->no_spans = false;
+#undef NA_HIP
+    if (lost)
+        return api_caught(h, PT_ERR_QUEUE_OVERFLOW,
+                          "ptgpu_render_noalloc: glass branching overflowed the queues that fit the static scratch; some samples of this "
+                          "call were not accumulated (use ptgpu_render, a smaller image or a smaller max_depth)");
+    return PT_OK;
 }
 
 int ptgpu_sync(PtHandle *h) {
