@@ -2,13 +2,18 @@
 """Headline benchmark: Mrays/s of the wavefront path tracer on the reference's sample scene at 1920x1080.
 
 One "step" = `--spp-per-step` samples per pixel over the whole 1080p image on every GPU (the reference's frame is
-1 spp: src/window.rs:166).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders
-its own sample-index shard and the u32 accumulators are summed once with RCCL inside the timed region.  Rank 0
-prints ONE JSON line.
+1 spp: src/window.rs:166).  With N > 1 there are two ways to drive the GPUs, both sample-index shards with ONE
+reduction of the u32 accumulators inside the timed region:
+  * launched by torch.distributed.run, one rank per GPU (the default): every rank owns a PtGpu handle, the
+    accumulators are summed with an RCCL all-reduce issued through torch.distributed;
+  * `--inproc`: ONE process, the library's own PtGroup (one handle + host thread per device, ncclReduce inside
+    libptgpu) - what a single-process host like the reference's window loop uses.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -19,6 +24,37 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+VALU_PEAK_GINST = 923.0  # wave64 v_fma_f32 issued per second chip-wide, measured (profiles/micro/valu_exec_mask.hip)
+
+
+def source_hash() -> str:
+    """Identifies the kernels a profile was taken from: a hash over the device sources.  Counter files under profiles/
+    carry the hash of the tree they were collected with; figures taken from them are marked stale when it differs."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pathtracer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_info() -> dict:
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    info = {"cpu_model": model, "host_nproc": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0))}
+    try:   # cgroup v2 CPU quota of this job, in CPUs
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_quota"] = None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        info["cgroup_cpu_quota"] = None
+    return info
 
 
 def cpu_baseline(sc, budget_s: float, threads: int, note: str = "the same", warm: bool = True, hoist_plane_axes: int = 0):
@@ -56,12 +92,40 @@ def cpu_baseline(sc, budget_s: float, threads: int, note: str = "the same", warm
     }
 
 
+def profile_figures(workload: str, kernel: str, avg_launch_s: float, here: str):
+    """HBM traffic and VALU figures of `kernel` from the committed counter run of the same command (profiles/), stamped
+    with the source hash they were collected under; `stale` when the kernels have changed since."""
+    tag = {"sample": "r02", "room": "r02_room", "quads": "r02_quads"}[workload]
+    traffic, valu, stamp = None, None, None
+    cpath = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
+    if not os.path.exists(cpath):
+        return None, None, None
+    try:
+        doc = json.load(open(cpath))
+        stamp = {"file": f"profiles/{tag}_counters.json", "source_hash": doc.get("_source_hash"), "commit": doc.get("_commit"),
+                 "stale": doc.get("_source_hash") != here}
+        ctr = doc.get(kernel, {})
+        if "hbm_bytes_per_launch" in ctr:
+            traffic = ctr["hbm_bytes_per_launch"]["total"]
+        insts = ctr["SQ_INSTS_VALU"]["per_launch"]
+        lanes = ctr["SQ_THREAD_CYCLES_VALU"]["per_launch"] / insts / 64.0
+        rate = insts / avg_launch_s / 1e9
+        valu = {"wave_insts_per_launch": round(insts), "achieved": round(rate, 1), "peak": VALU_PEAK_GINST,
+                "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK_GINST, 3), "lane_utilisation": round(lanes, 3),
+                "profile": stamp}
+    except Exception:
+        pass
+    return traffic, valu, stamp
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="32 steps of 32 spp: the 1024 spp the 1080p configuration is quoted on")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=0, help="0 = 32: several pipeline passes per step, so that a step is ~10-30 ms and the one all-reduce of a multi-GPU run is small beside it")
+    ap.add_argument("--steps", type=int, default=8, help="8 steps of 512 spp: four times the 1024 spp the 1080p configuration is quoted on")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="0 = 512 (32 for the BVH scene): a step is >= 0.1 s, so that 20 steps are >= 2 s of GPU time and the one "
+                         "reduction of a multi-GPU run is small beside them")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=0, help="0 = the workload's own (4; 16 for room)")
@@ -79,26 +143,31 @@ def main() -> None:
     ap.add_argument("--pipelined", action="store_true",
                     help="after the timed region, run the same steps again with the library's default of two passes in flight "
                          "(no per-kernel events) and report that throughput as `pipelined`")
+    ap.add_argument("--inproc", action="store_true",
+                    help="drive the --gpus devices from this one process through the library's PtGroup (in-library RCCL) "
+                         "instead of one torch.distributed rank per GPU")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events (no roofline block)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     from pathtracer_amd import binding, distributed as D, scene as S
 
     rank, world, local_rank = D.env_rank()
-    if world > 1 or os.environ.get("PTGPU_FORCE_COLLECTIVE"):
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    dev = torch.device("cuda", local_rank)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    dist = None
+    torch = None
+    if args.inproc:
+        assert world == 1, "--inproc is a single-process mode: do not launch it under torch.distributed.run"
+        n_gpus = max(1, args.gpus)
+    else:
+        import torch
+        import torch.distributed as dist
+        if world > 1 or os.environ.get("PTGPU_FORCE_COLLECTIVE"):
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+        n_gpus = world
+    use_dist = dist is not None and dist.is_initialized()
 
     if args.workload == "sample":
         sc = S.sample_scene(args.width, args.height, camera_width=5.0 * args.width / args.height)
@@ -113,39 +182,64 @@ def main() -> None:
         wl = f"closed diffuse room, 27 primitives (seed 777) at {args.width}x{args.height}"
         depth = args.max_depth or 16
     args.max_depth = depth
-    args.spp_per_step = args.spp_per_step or 32
+    args.spp_per_step = args.spp_per_step or (32 if args.workload == "quads" else 512)
     if args.passes < 0:
         args.passes = 0 if args.workload == "quads" else 1
-    gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, max_depth=args.max_depth,
-                        fuse_trace_shade=args.fused, samples_per_batch=args.batch, concurrent_passes=args.passes, accel=args.accel,
-                        profile_events=0 if args.no_events else 1)
+    cfg = dict(max_depth=args.max_depth, fuse_trace_shade=args.fused, samples_per_batch=args.batch, concurrent_passes=args.passes,
+               accel=args.accel, profile_events=0 if args.no_events else 1)
+
+    if args.inproc:
+        gpu = binding.PtGroup(n_devices=n_gpus, **cfg)
+        step_spp = args.spp_per_step * n_gpus      # weak scaling: every device renders spp_per_step per step
+
+        def barrier():
+            gpu.sync()
+
+        def exchange():
+            gpu.present_pixels8()                  # the reduction onto device 0 + the display bytes, as a window host ends a frame
+            return args.steps * step_spp
+    else:
+        dev = torch.device("cuda", local_rank)
+        gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world, **cfg)
+        step_spp = args.spp_per_step
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        def exchange():
+            total = D.combine_accumulators(gpu, args.steps * args.spp_per_step)
+            torch.cuda.synchronize(dev)
+            return total
+
     gpu.upload_scene(sc)
     for _ in range(args.warmup):
-        gpu.render(args.spp_per_step)
+        gpu.render(step_spp)
     gpu.sync()
-    if dist.is_initialized():
+    if args.inproc:
+        gpu.present_pixels8()                      # creates the RCCL communicators
+    elif use_dist:
         D.combine_accumulators(gpu, args.warmup * args.spp_per_step)  # warms RCCL up too
     gpu.clear()
 
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gpu.render(args.spp_per_step)
+        gpu.render(step_spp)
     gpu.sync()
     t_exchange = time.perf_counter()
-    total_spp = D.combine_accumulators(gpu, args.steps * args.spp_per_step)
-    torch.cuda.synchronize(dev)
-    t_exchange = time.perf_counter() - t_exchange   # export + RCCL all-reduce + import, inside the timed region
+    total_spp = exchange()
+    t_exchange = time.perf_counter() - t_exchange   # the one reduction of the job, inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
 
     st = gpu.stats()
     pipelined = None
-    if args.pipelined and world == 1:
+    if args.pipelined and n_gpus == 1 and not args.inproc:
         # the same steps with the library's default of two passes in flight (no per-kernel events)
         gpu.close()
-        gpu = binding.PtGpu(device=local_rank, max_depth=args.max_depth, fuse_trace_shade=args.fused, samples_per_batch=args.batch,
-                            concurrent_passes=0, accel=args.accel, profile_events=0)
+        gpu = binding.PtGpu(device=local_rank, **dict(cfg, concurrent_passes=0, profile_events=0))
         gpu.upload_scene(sc)
         for _ in range(args.warmup):
             gpu.render(args.spp_per_step)
@@ -158,28 +252,34 @@ def main() -> None:
         dt = time.perf_counter() - t1
         pipelined = {"value": round(gpu.stats()["rays"] / dt / 1e6, 2), "unit": "Mrays/s", "passes_in_flight": 2,
                      "ms_per_step": round(1e3 * dt / args.steps, 4)}
-    agg = torch.tensor([float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    rays, samples = float(st["rays"]), float(st["samples"])
+    if use_dist and world > 1:
+        agg = torch.tensor([rays, samples], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rays, samples, elapsed = float(agg[0].item()), float(agg[1].item()), float(tmax[0].item())
+        rays, samples, elapsed = float(agg[0].item()), float(agg[1].item()), float(tmax[0].item())
 
     if rank == 0:
+        here = source_hash()
         out = {
             "metric": f"Mrays/s (and sec-to-N-spp, field sec_to_1024_spp) at 1080p on {'scenes/sample' if args.workload == 'sample' else 'the ' + args.workload + ' stress scene'}; ray = one nearest-hit query: primary + bounce + shadow",
             "value": round(rays / elapsed / 1e6, 2),
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl}, max_depth {args.max_depth}, {args.spp_per_step} spp per step per GPU",
-                       "spp_per_step": args.spp_per_step, "parallelism": f"sample-index shards x{world}",
+                       "spp_per_step": args.spp_per_step,
+                       "parallelism": f"sample-index shards x{n_gpus}" + (", one process (PtGroup, in-library RCCL)" if args.inproc else ""),
                        "accumulated_spp": total_spp},
             "msamples_per_s": round(samples / elapsed / 1e6, 2),
             "sec_to_1024_spp": round(1024.0 * args.width * args.height / (samples / elapsed), 3),
             "rays_per_sample": round(rays / max(samples, 1.0), 3),
+            "timed_region_s": round(elapsed, 3),
+            "source_hash": here,
+            "queue_gib": round(st["queue_bytes"] / 2**30, 2),
         }
         if not args.no_events:
             # dominant kernel: the fused trace+shade launches (or trace, in the two-kernel pipeline)
@@ -202,51 +302,48 @@ def main() -> None:
                 alg = 0.0
             ms = kms[name]
             n_launch = max(1, kl[name])
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
-                except Exception:
-                    traffic = None
-            out["roofline"] = {
+            avg_s = ms * 1e-3 / n_launch
+            traffic, valu, stamp = profile_figures(args.workload, name, avg_s, here)
+            alg_rate = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof = {
                 "bound": "hbm", "kernel": name,
-                "achieved": round(alg / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else 0.0,
-                "traffic": traffic,
+                "achieved": round(alg_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg_rate / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_profile": stamp,
                 "launches": int(kl[name]), "avg_launch_ms": round(ms / n_launch, 5),
                 "algorithmic_bytes_per_launch": round(alg / n_launch, 1),
                 "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v > 0},
             }
-            # what actually binds the fused kernel: vector instruction issue.  Instruction counts per launch come from the
-            # committed counter run of the same command (profiles/), the duration is this run's; the peak is the measured
-            # issue rate of independent wave64 v_fma_f32 on this chip (profiles/micro/valu_exec_mask.hip).
-            cpath = os.path.join(ROOT, "profiles", {"sample": "r01_counters.json", "room": "r01_room_counters.json",
-                                                    "quads": "r01_quads_counters.json"}[args.workload])
-            try:
-                ctr = json.load(open(cpath)).get(name, {})
-                insts = ctr["SQ_INSTS_VALU"]["per_launch"]
-                lanes = ctr["SQ_THREAD_CYCLES_VALU"]["per_launch"] / insts / 64.0
-                rate = insts / (ms / n_launch * 1e-3) / 1e9
-                out["valu"] = {"wave_insts_per_launch": round(insts), "achieved": round(rate, 1), "peak": 923.0,
-                               "unit": "G wave-instructions/s", "frac": round(rate / 923.0, 3), "lane_utilisation": round(lanes, 3)}
-            except Exception:
-                pass
             if name == "trace":
-                out["roofline"]["note"] = ("64 bytes per traversal step are priced whether they come from HBM or from a cache; most node "
-                                           "fetches are cache hits, so this rate can exceed the HBM peak - `traffic` is what HBM saw")
-        if dist.is_initialized():
+                # The traversal's algorithmic bytes (64 per step) are mostly served by L1/L2: priced against HBM they can
+                # exceed its peak, which is no roofline.  The fraction reported is what HBM saw (counter traffic of the
+                # committed profile of this command over this run's launch time); the algorithmic rate stays as a field.
+                roof["algorithmic_rate_gbs"] = roof["achieved"]
+                hbm_rate = (traffic / avg_s / 1e9) if (traffic and avg_s > 0) else None
+                roof["achieved"] = round(hbm_rate, 2) if hbm_rate is not None else None
+                roof["frac"] = round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate is not None else None
+                roof["note"] = ("BVH traversal: `achieved`/`frac` are HBM-side (counter bytes per launch / launch time); "
+                                "`algorithmic_rate_gbs` prices 64 B per traversal step wherever it is served from")
+            out["roofline"] = roof
+            if valu is not None:
+                # what actually binds the fused kernel: vector instruction issue (see `limiter`)
+                out["valu"] = valu
+                out["roofline"]["limiter"] = "valu_issue" if valu["frac"] > out["roofline"]["frac"] else "hbm"
+        if use_dist or args.inproc:
             # the one exchange step of the job (this rank's wall time for it: waiting for the slowest rank included)
-            out["exchange"] = {"op": "all_reduce(SUM) of the u32 accumulator, once per timed region",
+            out["exchange"] = {"op": ("ncclReduce(SUM, u32) onto device 0 + pixels8 readback (PtGroup)" if args.inproc
+                                      else "all_reduce(SUM) of the u32 accumulator") + ", once per timed region",
                                "bytes": args.width * args.height * 12, "ms": round(1e3 * t_exchange, 3)}
+            if args.inproc:
+                out["exchange"]["device_ms"] = round(gpu.exchange_stats()["ms"], 3)
         if pipelined is not None:
             out["pipelined"] = pipelined
         out["config"]["passes_in_flight"] = args.passes if args.passes else 2
         if st["bvh_nodes"]:
-            out["bvh"] = {"nodes": st["bvh_nodes"], "leaf_prims": st["bvh_leaf_prims"],
+            out["bvh"] = {"nodes": st["bvh_nodes"], "leaf_prims": st["bvh_leaf_prims"], "depth": st["bvh_depth"],
                           "steps_per_traced_ray": round(st["bvh_steps"] / max(1, st["rays"] - st["shadow_rays"]), 2)}
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            host = host_info()
             if args.workload == "quads":
                 # the reference scans every primitive per ray (src/scene.rs:263-297): ~1M tests per ray, so the
                 # bounded sample is the same scene and camera at 128x64 pixels (8 full tiles, one per thread)
@@ -254,18 +351,19 @@ def main() -> None:
                 out["cpu_baseline"] = cpu_baseline(small, 1.0, 8, "the same (linear scan, reduced image)", warm=False)
             else:
                 out["cpu_baseline"] = cpu_baseline(sc, args.cpu_baseline_seconds, 8)
-                # beside the faithful 8-thread figure: the same pool with per-plane axes hoisted out of the ray loop, and
-                # the faithful code on this process's share of the host (at most 16 threads)
-                share = max(1, min(16, len(os.sched_getaffinity(0))))
+                # beside the faithful 8-thread figure (the reference's constant, src/window.rs:110): the same pool with
+                # per-plane axes hoisted out of the ray loop, and the faithful code on every CPU this process may run on
+                nproc = max(1, host["affinity_cpus"])
                 hoisted = cpu_baseline(sc, args.cpu_baseline_seconds / 4, 8, hoist_plane_axes=1)
-                wide = cpu_baseline(sc, args.cpu_baseline_seconds / 4, share)
+                wide = cpu_baseline(sc, args.cpu_baseline_seconds / 4, nproc)
                 out["cpu_baseline"]["variants"] = {
                     "plane_axes_hoisted_8_threads": {"value": hoisted["value"], "unit": "Mrays/s", "cores": 8},
-                    f"faithful_{share}_threads": {"value": wide["value"], "unit": "Mrays/s", "cores": share}}
+                    "faithful_nproc_threads": {"value": wide["value"], "unit": "Mrays/s", "cores": nproc}}
+            out["cpu_baseline"].update(host)
         print(json.dumps(out), flush=True)
 
     gpu.close()
-    if dist.is_initialized():
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

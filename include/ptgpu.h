@@ -214,6 +214,39 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out);
 int ptgpu_bvh_build_stats(const PtSceneDesc *scene, PtStats *out);
 const char *ptgpu_last_error(PtHandle *h);
 
+/* ---- Several GPUs of one node behind one handle ----------------------------------------------------------------
+ * Replaces the same pair as ptgpu_create/ptgpu_render - WorkerPool::new(8, ...) (src/window.rs:109-116) and the
+ * per-frame process(tile) x tiles + wait() (src/window.rs:166-196) - for a single-process host with more than one
+ * GPU: the devices take the place of the pool's worker threads.  The group owns one PtHandle and one host thread
+ * per device; device k renders the global sample indices s with s % n == k for all pixels (scene replicated), and
+ * the u32 accumulators are summed onto the first device with RCCL (ncclReduce, ncclUint32/ncclSum, over xGMI) when
+ * the image is read - the only exchange.  Integer sums and an RNG keyed on the global sample index make pixels32 /
+ * pixels8 bit-identical to what one handle renders for the same total number of samples.
+ * cfg->device, shard_index and shard_count are ignored (set per member).  devices == NULL: ordinals 0..n-1;
+ * n_devices == 0: every visible device.  Calls on one group come from one host thread at a time. */
+typedef struct PtGroup PtGroup;
+int ptgpu_group_create(const PtConfig *cfg, const int32_t *devices, uint32_t n_devices, PtGroup **out);
+void ptgpu_group_destroy(PtGroup *g);
+int ptgpu_group_upload_scene(PtGroup *g, const PtSceneDesc *scene);   /* every `*scene = ...; backbuffer.clear()` site, src/window.rs:130-163 */
+int ptgpu_group_clear(PtGroup *g);                                    /* Backbuffer::clear, src/tracer.rs:242-256 */
+/* n_samples more samples per pixel IN TOTAL, split over the devices by sample index (src/window.rs:166-196 x n_samples);
+ * returns when the work is enqueued on every device. */
+int ptgpu_group_render(PtGroup *g, uint32_t n_samples);
+int ptgpu_group_sync(PtGroup *g);
+/* Backbuffer.pixels32 / pixels8 / the bytes for glDrawPixels (src/window.rs:205-210) of everything rendered so far;
+ * each call synchronises the devices and runs the one reduction. */
+int ptgpu_group_read_pixels32(PtGroup *g, uint32_t *out, uint64_t *num_samples);
+int ptgpu_group_read_pixels8(PtGroup *g, uint8_t *out);
+int ptgpu_group_present_pixels8(PtGroup *g, const uint8_t **pixels);
+int ptgpu_group_get_stats(PtGroup *g, PtStats *out);                  /* counts and times summed over the devices */
+int ptgpu_group_exchange_stats(PtGroup *g, uint64_t *bytes, double *ms);  /* size and device time of the last reduction */
+/* The split rule itself (pure arithmetic, no device): how many of the global sample indices first .. first+count-1
+ * are congruent to k modulo n, i.e. go to device k of n. */
+uint64_t ptgpu_group_shard_samples(uint64_t first, uint64_t count, uint32_t k, uint32_t n);
+uint32_t ptgpu_group_size(const PtGroup *g);
+PtHandle *ptgpu_group_member(PtGroup *g, uint32_t k);                 /* device k's handle (stats, stream); owned by the group */
+const char *ptgpu_group_last_error(PtGroup *g);
+
 /* What the Rust host computes with hmath before the scene reaches this library; provided for C/C++/
  * Python hosts.  Camera::new (src/tracer.rs:69-96) and Plane::new's normal (src/scene.rs:106). */
 void ptgpu_camera_new(PtVec3 position, PtVec3 target, PtVec3 up, float width, float height, float z_near,

@@ -102,6 +102,30 @@ def load_library() -> C.CDLL:
     lib.ptgpu_export_pixels32.argtypes = [H, C.c_void_p]
     lib.ptgpu_import_pixels32.argtypes = [H, C.c_void_p, C.c_uint64]
     lib.ptgpu_get_stats.argtypes = [H, C.POINTER(PtStats)]
+    G = C.c_void_p
+    lib.ptgpu_group_create.argtypes = [C.POINTER(PtConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(G)]
+    lib.ptgpu_group_destroy.argtypes = [G]
+    lib.ptgpu_group_destroy.restype = None
+    lib.ptgpu_group_upload_scene.argtypes = [G, C.POINTER(PtSceneDesc)]
+    lib.ptgpu_group_clear.argtypes = [G]
+    lib.ptgpu_group_render.argtypes = [G, C.c_uint32]
+    lib.ptgpu_group_sync.argtypes = [G]
+    lib.ptgpu_group_read_pixels32.argtypes = [G, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.ptgpu_group_read_pixels8.argtypes = [G, C.c_void_p]
+    lib.ptgpu_group_present_pixels8.argtypes = [G, C.POINTER(C.c_void_p)]
+    lib.ptgpu_group_get_stats.argtypes = [G, C.POINTER(PtStats)]
+    lib.ptgpu_group_exchange_stats.argtypes = [G, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.ptgpu_group_shard_samples.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.ptgpu_group_shard_samples.restype = C.c_uint64
+    lib.ptgpu_group_size.argtypes = [G]
+    lib.ptgpu_group_size.restype = C.c_uint32
+    lib.ptgpu_group_member.argtypes = [G, C.c_uint32]
+    lib.ptgpu_group_member.restype = C.c_void_p
+    lib.ptgpu_group_last_error.argtypes = [G]
+    lib.ptgpu_group_last_error.restype = C.c_char_p
+    for name in ("create", "upload_scene", "clear", "render", "sync", "read_pixels32", "read_pixels8", "present_pixels8", "get_stats",
+                 "exchange_stats"):
+        getattr(lib, "ptgpu_group_" + name).restype = C.c_int
     lib.ptgpu_bvh_build_stats.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtStats)]
     lib.ptgpu_bvh_build_stats.restype = C.c_int
     lib.ptgpu_last_error.argtypes = [H]
@@ -197,6 +221,92 @@ def _stats_dict(st: PtStats) -> dict:
         "bvh_forced_median_splits": st.bvh_forced_median_splits, "bvh_level_fold": st.bvh_level_fold,
         "queue_bytes": st.queue_bytes,
     }
+
+
+class PtGroup:
+    """Several GPUs of one node behind one handle, driven from this one process (ptgpu_group_*): what a single-process host
+    like the reference's window loop (reference src/window.rs:104-213) uses in place of PtGpu when it has more than one
+    GPU.  `devices` = list of HIP ordinals, or None with n_devices = 0 for all visible ones."""
+
+    def __init__(self, devices=None, n_devices: int = 0, cfg: Optional[PtConfig] = None, **overrides):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config(**overrides)
+        self.g = C.c_void_p()
+        arr = None
+        if devices is not None:
+            n_devices = len(devices)
+            arr = (C.c_int32 * n_devices)(*devices)
+        rc = self.lib.ptgpu_group_create(C.byref(self.cfg), arr, n_devices, C.byref(self.g))
+        if rc != 0:
+            self.g = C.c_void_p()
+            raise PtGpuError(rc, "ptgpu_group_create failed (gfx950 GPUs are required)")
+        self.width = self.height = 0
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise PtGpuError(rc, (self.lib.ptgpu_group_last_error(self.g) or b"").decode())
+
+    def close(self) -> None:
+        if self.g:
+            self.lib.ptgpu_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def size(self) -> int:
+        return int(self.lib.ptgpu_group_size(self.g))
+
+    def upload_scene(self, scene: S.Scene) -> None:
+        sd = SceneDesc(scene)
+        self._chk(self.lib.ptgpu_group_upload_scene(self.g, C.byref(sd.desc)))
+        self.width, self.height = scene.image_settings.width, scene.image_settings.height
+
+    def clear(self) -> None:
+        self._chk(self.lib.ptgpu_group_clear(self.g))
+
+    def render(self, n_samples: int) -> None:
+        self._chk(self.lib.ptgpu_group_render(self.g, int(n_samples)))
+
+    def sync(self) -> None:
+        self._chk(self.lib.ptgpu_group_sync(self.g))
+
+    def read_pixels32(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint32)
+        n = C.c_uint64()
+        self._chk(self.lib.ptgpu_group_read_pixels32(self.g, out.ctypes.data, C.byref(n)))
+        return out, int(n.value)
+
+    def read_pixels8(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._chk(self.lib.ptgpu_group_read_pixels8(self.g, out.ctypes.data))
+        return out
+
+    def present_pixels8(self) -> np.ndarray:
+        p = C.c_void_p()
+        self._chk(self.lib.ptgpu_group_present_pixels8(self.g, C.byref(p)))
+        buf = (C.c_uint8 * (self.height * self.width * 3)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
+
+    def stats(self) -> dict:
+        st = PtStats()
+        self._chk(self.lib.ptgpu_group_get_stats(self.g, C.byref(st)))
+        return _stats_dict(st)
+
+    def exchange_stats(self) -> dict:
+        b, ms = C.c_uint64(), C.c_double()
+        self._chk(self.lib.ptgpu_group_exchange_stats(self.g, C.byref(b), C.byref(ms)))
+        return {"bytes": int(b.value), "ms": float(ms.value)}
 
 
 class PtGpu:

@@ -1254,3 +1254,5 @@ int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, flo
 }
 
 }  // extern "C"
+
+#include "pt_group.h"

@@ -1,19 +1,18 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py's default run on the GPU box (run through gpurun from the repo
 # root).  Kernel times and hardware counters come from SEPARATE runs (counters never together with tracing).
-# Usage: bash profiles/collect.sh <tag> [workload]   -> gpurun_out/<tag>_*   (copy what should be kept into profiles/)
+# Usage: PT_COMMIT=<git rev> bash profiles/collect.sh <tag> [workload]   -> gpurun_out/<tag>_*   (copy what should be kept into profiles/)
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 WL=${2:-sample}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-STEPS=16; SSTEPS=4
-if [ "$WL" != sample ]; then STEPS=4; SSTEPS=2; fi
-BENCH="python3 bench.py --workload $WL --steps $STEPS --warmup 2 --no-cpu-baseline"
+STEPS=4; SSTEPS=1
+BENCH="python3 bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $BENCH > $OUT/${TAG}_trace.log 2>&1
 cp "$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats.csv
 grep '^{' $OUT/${TAG}_trace.log > $OUT/${TAG}_bench_under_rocprof.json || true
-SHORT="python3 bench.py --workload $WL --steps $SSTEPS --warmup 1 --no-cpu-baseline --no-events"
+SHORT="python3 bench.py --workload $WL --steps $SSTEPS --warmup 0 --spp-per-step 64 --no-cpu-baseline --no-events"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- $SHORT > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- $SHORT > $OUT/${TAG}_pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/${TAG}_pmc_sq -- $SHORT > $OUT/${TAG}_pmc_sq.log 2>&1

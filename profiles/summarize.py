@@ -1,4 +1,7 @@
 """Folds the rocprofv3 counter CSVs written by profiles/collect.sh into per-kernel, per-launch numbers.
+The output carries `_source_hash` (bench.py's hash over the device sources the run was built from) and `_commit`
+(git revision, handed in through PT_COMMIT: the GPU box has no .git), so that a reader - bench.py included - can
+tell whether the figures belong to the kernels it is looking at.
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-byte request of a wide coalesced
 read, i.e. half the bytes: it is doubled here (this pipeline reads 16 B per lane from consecutive records).
@@ -9,7 +12,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402
 
 out, tag = sys.argv[1], sys.argv[2]
 CLASS = [("k_shade<true", "trace_shade"), ("k_shade<false", "shade"), ("k_trace", "trace"), ("k_terminal", "terminal"),
@@ -44,6 +51,8 @@ for c, v in agg.items():
         wr = 1024.0 * res[c]["WRITE_SIZE"]["per_launch"]
         res[c]["hbm_bytes_per_launch"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr}
         traffic[c] = rd + wr
+res["_source_hash"] = source_hash()
+res["_commit"] = os.environ.get("PT_COMMIT", "unknown")
 json.dump(res, open(f"{out}/{tag}_counters.json", "w"), indent=1)
 json.dump(traffic, open(f"{out}/{tag}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(traffic))

@@ -1,6 +1,8 @@
 /* A host written in plain C99 against include/ptgpu.h: what a cgo / Rust-bindgen / ctypes consumer sees.
  * Renders a few samples of a two-primitive scene and prints the accumulator's checksum; the Python test compares it
- * with the same scene rendered through the ctypes binding. */
+ * with the same scene rendered through the ctypes binding.  Then the same frames through a one-device PtGroup (the
+ * in-library multi-GPU path, RCCL reduction included) in the window loop's pattern - one sample and one present per
+ * frame - which must print the same sums. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,7 +55,30 @@ int main(int argc, char **argv) {
     const uint8_t *shown = NULL;
     if ((rc = ptgpu_present_pixels8(h, &shown)) != PT_OK) return 5;
     printf("samples %llu sum %llu fnv %llu first_byte %u\n", (unsigned long long)n, (unsigned long long)sum, (unsigned long long)mix, (unsigned)shown[0]);
-    free(p32);
     ptgpu_destroy(h);
+
+    {
+        PtGroup *g = NULL;
+        int32_t device = 0;
+        uint32_t frame;
+        uint64_t gn = 0, gsum = 0, gmix = 1469598103934665603ull, bytes = 0;
+        double ms = 0.0;
+        const uint8_t *gshown = NULL;
+        if ((rc = ptgpu_group_create(&cfg, &device, 1, &g)) != PT_OK) { fprintf(stderr, "ptgpu_group_create: %d\n", rc); return 6; }
+        if ((rc = ptgpu_group_upload_scene(g, &sc)) != PT_OK) { fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g)); return 7; }
+        for (frame = 0; frame < spp; ++frame) {   /* src/window.rs:127-213: one sample per frame, then present */
+            if ((rc = ptgpu_group_render(g, 1)) != PT_OK || (rc = ptgpu_group_present_pixels8(g, &gshown)) != PT_OK) {
+                fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g));
+                return 8;
+            }
+        }
+        if ((rc = ptgpu_group_read_pixels32(g, p32, &gn)) != PT_OK) { fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g)); return 9; }
+        for (int i = 0; i < 32 * 24 * 3; ++i) { gsum += p32[i]; gmix = (gmix ^ p32[i]) * 1099511628211ull; }
+        ptgpu_group_exchange_stats(g, &bytes, &ms);
+        printf("group devices %u samples %llu sum %llu fnv %llu first_byte %u exchange_bytes %llu\n", (unsigned)ptgpu_group_size(g),
+               (unsigned long long)gn, (unsigned long long)gsum, (unsigned long long)gmix, (unsigned)gshown[0], (unsigned long long)bytes);
+        ptgpu_group_destroy(g);
+    }
+    free(p32);
     return 0;
 }

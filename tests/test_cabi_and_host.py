@@ -83,3 +83,31 @@ def test_header_is_plain_c99():
     import subprocess
     src = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), src])
+
+
+def test_group_split_rule_partitions_the_sample_indices(binding):
+    """ptgpu_group_shard_samples(first, count, k, n) = |{s in [first, first+count) : s % n == k}|: over k the counts
+    partition every call, and over calls device k receives exactly its congruence class, in order."""
+    lib = binding.load_library()
+    rng = np.random.RandomState(3)
+    for n in (1, 2, 3, 4, 7, 8):
+        first = 0
+        seen = [0] * n
+        for _ in range(40):
+            count = int(rng.randint(0, 20))
+            got = [lib.ptgpu_group_shard_samples(first, count, k, n) for k in range(n)]
+            want = [sum(1 for s in range(first, first + count) if s % n == k) for k in range(n)]
+            assert got == want and sum(got) == count
+            for k in range(n):
+                seen[k] += got[k]
+            first += count
+        assert seen == [sum(1 for s in range(first) if s % n == k) for k in range(n)]
+    assert lib.ptgpu_group_shard_samples(0, 10, 3, 3) == 0 and lib.ptgpu_group_shard_samples(0, 10, 0, 0) == 0
+    assert lib.ptgpu_group_shard_samples(2**40, 2**33, 5, 8) == 2**30
+
+
+def test_library_links_rccl_itself():
+    """The multi-GPU reduction is the library's own (ncclReduce from pt_group.h), not a Python-side collective."""
+    import subprocess
+    out = subprocess.check_output(["readelf", "-d", os.path.join(ROOT, "pathtracer_amd", "libptgpu.so")], text=True)
+    assert "librccl.so" in out

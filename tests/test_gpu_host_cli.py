@@ -101,7 +101,8 @@ def test_plain_c_host_renders_the_same(binding):
     exe = os.path.join(ROOT, "tests", "c", "abi_smoke")
     r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    words = r.stdout.split()
+    lines = r.stdout.strip().splitlines()
+    words = lines[0].split()
     got = dict(zip(words[0::2], (int(w) for w in words[1::2])))
     sc = S.Scene(image_settings=S.ImageSettings(32, 24, True),
                  camera=S.Camera((0.0, 2.0, 6.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 4.0, 3.0, 2.0, S.TONE_CLAMP, 1.0, 100.0),
@@ -114,3 +115,9 @@ def test_plain_c_host_renders_the_same(binding):
         p32, n = gpu.read_pixels32()
         p8 = gpu.read_pixels8()
     assert got["samples"] == n == 3 and got["sum"] == int(p32.astype(np.uint64).sum()) and got["first_byte"] == int(p8.reshape(-1)[0])
+    # the same frames through a one-device PtGroup (one sample + one present per frame, RCCL reduction at every present)
+    gw = [ln for ln in lines if ln.startswith("group ")][0].split()   # (RCCL prints a version banner of its own)
+    grp = dict(zip(gw[1::2], (int(w) for w in gw[2::2])))
+    assert grp["devices"] == 1 and grp["exchange_bytes"] == 32 * 24 * 12
+    for key in ("samples", "sum", "fnv", "first_byte"):
+        assert grp[key] == got[key], key
