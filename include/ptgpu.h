@@ -140,6 +140,7 @@ typedef struct {
     uint64_t bvh_forced_median_splits;        /* splits the builder took at the object median to stay under that cap */
     uint64_t bvh_level_fold;                  /* 1: the 4-wide tree was folded level by level because folding by box area was too deep */
     uint64_t queue_bytes;                     /* the part of device_bytes held by the ray queue levels */
+    uint64_t level_records[25];               /* queue records per path-tree level since clear (level 0 = primary rays, level max_depth = terminal light samples) */
 } PtStats;
 
 typedef struct PtHandle PtHandle;

@@ -167,6 +167,7 @@ pub struct PtStats {
     pub bvh_forced_median_splits: u64,
     pub bvh_level_fold: u64,
     pub queue_bytes: u64,
+    pub level_records: [u64; 25],
 }
 
 pub enum PtHandle {}

@@ -341,6 +341,7 @@ int ptgpu_group_get_stats(PtGroup *g, PtStats *out) {
         out->terminal_records += s.terminal_records; out->bvh_steps += s.bvh_steps;
         out->device_bytes += s.device_bytes; out->queue_bytes += s.queue_bytes;
         for (int k = 0; k < PT_KERNEL_COUNT; ++k) { out->kernel_launches[k] += s.kernel_launches[k]; out->kernel_ms[k] += s.kernel_ms[k]; }
+        for (int l = 0; l < 25; ++l) out->level_records[l] += s.level_records[l];
         // (the same on every device)
         out->bvh_nodes = s.bvh_nodes; out->bvh_leaf_prims = s.bvh_leaf_prims; out->bvh_depth = s.bvh_depth;
         out->bvh_binary_depth = s.bvh_binary_depth; out->bvh_forced_median_splits = s.bvh_forced_median_splits;

@@ -39,10 +39,14 @@ constexpr int BLOCK = 256;
 #endif
 
 struct Level {
-    // One allocation per level, carved into SoA arrays of n = NSHARD * shard_cap records: the five 16-byte arrays
+    // One allocation per level, carved into SoA arrays of n = NSHARD * shard_cap records: the three 16-byte arrays
     // first, then the four 4-byte ones.  Only the base is passed to the kernels (three Levels of ten pointers each
     // cost 60 scalar registers and pushed the fused kernel into spilling them); the accessors below rebuild the
     // array addresses with a few scalar instructions.
+    //
+    // A record's ray is dead once the record has been shaded, and its children's radiance only arrives after that
+    // (from the next level's launch, the terminal kernel or the backward sweep): the two share storage.  val0 is
+    // rayA's array and val1 rayB's, which is what keeps a record at 64 bytes.
     char *base;
     uint32_t *count;    // [NSHARD * CSTRIDE] records per shard, shard q at count[q * CSTRIDE]
     uint32_t *overflow; // this pass's flag: set when an append found a level full (the pass is then not accumulated)
@@ -51,13 +55,13 @@ struct Level {
     PT_HD float4 *rayA() const { return reinterpret_cast<float4 *>(base); }                  // (origin.xyz, dir.x)
     PT_HD float4 *rayB() const { return reinterpret_cast<float4 *>(base + 16 * n()); }       // (dir.y, dir.z, bits(rng key), bits(path node))
     PT_HD float4 *coef() const { return reinterpret_cast<float4 *>(base + 32 * n()); }       // node coefficients (xyz, w)
-    PT_HD float4 *val0() const { return reinterpret_cast<float4 *>(base + 48 * n()); }       // radiance of child 0
-    PT_HD float4 *val1() const { return reinterpret_cast<float4 *>(base + 64 * n()); }       // radiance of child 1 (glass reflection)
-    PT_HD uint32_t *parent() const { return reinterpret_cast<uint32_t *>(base + 80 * n()); } // (parent record index << 1) | child slot
-    PT_HD uint32_t *hitprim() const { return reinterpret_cast<uint32_t *>(base + 84 * n()); } // nearest hit: primitive id | HIT_OUT_BIT if Transition::Out, or MISS
-    PT_HD float *hit_t() const { return reinterpret_cast<float *>(base + 88 * n()); }        // its distance (with hitprim: two-kernel and trace-ahead pipelines)
-    PT_HD uint32_t *meta() const { return reinterpret_cast<uint32_t *>(base + 92 * n()); }   // node kind
-    static constexpr size_t RECORD_BYTES = 96;
+    PT_HD float4 *val0() const { return rayA(); }                                            // radiance of child 0 (after shading)
+    PT_HD float4 *val1() const { return rayB(); }                                            // radiance of child 1, the glass reflection (after shading)
+    PT_HD uint32_t *parent() const { return reinterpret_cast<uint32_t *>(base + 48 * n()); } // (parent record index << 1) | child slot
+    PT_HD uint32_t *hitprim() const { return reinterpret_cast<uint32_t *>(base + 52 * n()); } // nearest hit: primitive id | HIT_OUT_BIT if Transition::Out, or MISS
+    PT_HD float *hit_t() const { return reinterpret_cast<float *>(base + 56 * n()); }        // its distance (with hitprim: two-kernel and trace-ahead pipelines)
+    PT_HD uint32_t *meta() const { return reinterpret_cast<uint32_t *>(base + 60 * n()); }   // node kind
+    static constexpr size_t RECORD_BYTES = 64;
 };
 
 struct PassParams {
@@ -67,7 +71,8 @@ struct PassParams {
 };
 
 // device-side counters (one allocation)
-struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow, bvh_steps, terminal; unsigned long long stamps[8]; };
+struct Counters { uint32_t overflow; uint32_t pad; unsigned long long rays, records, shadow, bvh_steps, terminal; unsigned long long stamps[8];
+                  unsigned long long level_records[25]; };
 
 // Diagnostic builds (-DPT_STAMPS) time the phases of the fused kernel with s_memtime; never part of a shipped build.
 #ifdef PT_STAMPS
@@ -885,6 +890,9 @@ __global__ void k_account(const uint32_t *counts, const uint32_t *shard_caps, in
         unsigned long long n = c < cap ? c : cap;
         rec += n;
         if (l < n_levels - 1) rays += n; else terminal = n;
+        unsigned long long level_total = n;   // records of this level over all shards
+        for (int o = 32; o > 0; o >>= 1) level_total += __shfl_down(level_total, o);
+        if (q == 0 && l < 25) ctr->level_records[l] += level_total;
     }
     if (ahead) rays = counts[((n_levels + 1) * NSHARD + q) * CSTRIDE];
     unsigned long long shadow = counts[(n_levels * NSHARD + q) * CSTRIDE];

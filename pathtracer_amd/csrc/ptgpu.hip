@@ -1136,6 +1136,7 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         out->bvh_steps = c.bvh_steps;
         out->queue_growth = h->has_glass ? h->growth : 1u;
         out->terminal_records = c.terminal;
+        for (int l = 0; l < 25; ++l) out->level_records[l] = c.level_records[l];
         out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
     }
     out->bvh_nodes = h->bvh_nodes;
