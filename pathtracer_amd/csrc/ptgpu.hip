@@ -92,7 +92,7 @@ struct PtHandle {
     // Levels of a scene with glass are sized for `growth`-fold branching, not for the worst case 2^depth.  Every pass
     // has an overflow flag; a pass that filled a level adds nothing to the accumulator and is repeated, after the
     // levels have been re-allocated with twice the growth, when the host next synchronises.
-    uint32_t growth = 2;
+    uint32_t growth = 1;
     bool fixed_capacity = false;       // PtConfig.branch_capacity given: no re-allocation, overflow is an error
     uint32_t *d_flags = nullptr;       // [FLAG_RING] one flag per pass in flight
     uint64_t flag_cursor = 0;
@@ -325,20 +325,20 @@ int alloc_levels(PtHandle *h) {
     const int D = h->cfg.max_depth;
     h->n_levels = D + 1;
     const uint32_t branch_cap = h->growth;
-    // samples per pixel per pass: about 32M records at level 0 (fewer, larger launches), bounded by a
+    // samples per pixel per pass: about 64M records at level 0 (fewer, larger launches), bounded by a
     // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
     uint32_t b = h->cfg.samples_per_batch;
     // (measured on the sample scene at 1080p, one pass in flight: 8M records 24.1, 16M 25.3, 32M 26.3, 64M 27.8 Grays/s -
     // every kernel boundary drains the chip once; with two passes in flight the steps are 28.4 / 28.7 / 29.0.  BVH
     // scenes gain more: a launch ends with a few rays that walk hundreds of nodes and longer launches dilute that)
-    const uint64_t target = 32u << 20;
+    const uint64_t target = 64u << 20;
     if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
     const uint64_t rec_bytes = Level::RECORD_BYTES;
-    const uint64_t budget = 96ull << 30;  // of the 288 GB of an MI355X
+    const uint64_t budget = 48ull << 30;  // of the 288 GB of an MI355X, over all passes in flight
     for (;;) {
         uint64_t total = 0;
         for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4 * pipes_wanted(h);
@@ -824,7 +824,9 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     if ((rc = dev_alloc(h, &h->d_flags, (size_t)FLAG_RING))) return rc;
     HIPCHK(h, hipMemset(h->d_flags, 0, FLAG_RING * 4));
     h->fixed_capacity = h->cfg.branch_capacity != 0;
-    h->growth = h->fixed_capacity ? h->cfg.branch_capacity : 2u;
+    // Levels start at one record per sample and level (plus the 25 % slack of every shard): in the reference's scene 0.57 -
+    // 0.71 records per sample reach levels 1-3, glass included.  Scenes that branch more overflow once and grow.
+    h->growth = h->fixed_capacity ? h->cfg.branch_capacity : 1u;
     h->flag_cursor = 0;
     h->pending.clear();
     if ((rc = alloc_levels(h))) return rc;
@@ -906,7 +908,7 @@ int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
     for (Pipe &p : h->pipes) if (p.stream) NA_HIP(hipStreamSynchronize(p.stream));
     const uint64_t P = (uint64_t)h->sc.width * h->sc.height;
     const int n_levels = h->cfg.max_depth + 1;
-    uint32_t growth = h->fixed_capacity ? h->cfg.branch_capacity : 2u;
+    uint32_t growth = h->fixed_capacity ? h->cfg.branch_capacity : 1u;
     ScratchPlan pl;
     auto largest_pass = [&](uint32_t want) -> uint32_t {   // most samples per pass (<= want) whose queues fit the scratch; 0: not even one
         uint32_t spp = std::min<uint32_t>(want, 64);

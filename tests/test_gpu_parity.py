@@ -314,7 +314,7 @@ def _glass_scene(w, h):
 
 @pytest.mark.parametrize("pipes", [1, 2])
 def test_levels_grow_and_voided_passes_are_rendered_again(binding, oracle, pipes):
-    """With branch_capacity left at 0 the levels start small (2-fold branching).  Passes that overflow add nothing,
+    """With branch_capacity left at 0 the levels start small (one record per sample and level).  Passes that overflow add nothing,
     the levels are re-allocated larger and exactly those sample ranges are rendered again: the sums, the 8-bit
     image and the ray count are the oracle's, whichever passes had to be repeated and in whatever order."""
     sc = _glass_scene(96, 80)
@@ -322,7 +322,7 @@ def test_levels_grow_and_voided_passes_are_rendered_again(binding, oracle, pipes
     with binding.PtGpu(max_depth=depth, samples_per_batch=2, concurrent_passes=pipes) as gpu:
         gpu.upload_scene(sc)
         before = gpu.stats()
-        assert before["queue_growth"] == 2
+        assert before["queue_growth"] == 1
         gpu.render(3)
         gpu.render(4)
         p32, n = gpu.read_pixels32()
