@@ -84,13 +84,15 @@ __device__ __forceinline__ float slab_reciprocal(float d) {
 
 // A candidate replaces the current nearest when (t, id) is lexicographically smaller.
 // While nothing is hit, best == MISS (the largest id) and best_t == +inf, so the first hit always wins.
-__device__ __forceinline__ void bvh_accept(bool hit, float t, uint32_t id, int out, uint32_t &best, float &best_t, int &best_out) {
-    if (hit && (t < best_t || (t == best_t && id < best))) { best = id; best_t = t; best_out = out; }
+// `slot`: where the primitive's shading row is (its position in bvh_geom, or behind them for the `always` list).
+__device__ __forceinline__ void bvh_accept(bool hit, float t, uint32_t id, int out, uint32_t slot, uint32_t &best, float &best_t, int &best_out,
+                                           uint32_t &best_slot) {
+    if (hit && (t < best_t || (t == best_t && id < best))) { best = id; best_t = t; best_out = out; best_slot = slot; }
 }
 
 // Primitives outside the tree (the `always` list), by id through the scene tables.
 __device__ __forceinline__ void bvh_test_prims(const DevScene &sc, const uint32_t *ids, uint32_t n, V3 o, V3 d, uint32_t &best, float &best_t,
-                                               int &best_out) {
+                                               int &best_out, uint32_t &best_slot) {
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t id = ids[k];
         float t;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void bvh_test_prims(const DevScene &sc, const uint32_
             V3 pos;
             hit = plane_test(sc.pln[4 * p], sc.pln[4 * p + 1], sc.pln[4 * p + 2], sc.pln[4 * p + 3], o, d, t, pos);
         }
-        bvh_accept(hit, t, id, out, best, best_t, best_out);
+        bvh_accept(hit, t, id, out, sc.n_leaf_prims + k, best, best_t, best_out, best_slot);
     }
 }
 
@@ -144,6 +146,7 @@ struct Trav {
     uint32_t best;
     float best_t;
     int best_out;        // Transition of the best hit (1: a sphere left from inside)
+    uint32_t best_slot;  // its row in sc.shade_rows
     int32_t node;
     int sp;
     uint32_t leaf_cur, leaf_end;
@@ -174,7 +177,8 @@ __device__ __forceinline__ void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &
     s.best = MISS;
     s.best_t = __builtin_inff();
     s.best_out = 0;
-    bvh_test_prims(sc, sc.bvh_always, sc.n_always, o, d, s.best, s.best_t, s.best_out);
+    s.best_slot = MISS;
+    bvh_test_prims(sc, sc.bvh_always, sc.n_always, o, d, s.best, s.best_t, s.best_out, s.best_slot);
     s.inv = v3(slab_reciprocal(d.x), slab_reciprocal(d.y), slab_reciprocal(d.z));
     s.noi = v3(-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z));
     s.node = 0;
@@ -183,14 +187,14 @@ __device__ __forceinline__ void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &
 }
 
 // One primitive record of bvh_geom against the ray.
-__device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, float4 b, float4 c, float4 e, Trav &s) {
+__device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, float4 b, float4 c, float4 e, uint32_t slot, Trav &s) {
     uint32_t id = __float_as_uint(e.w);
     float t;
     bool hit;
     int out = 0;
     if (id < sc.n_sph) hit = sphere_test(a, s.o, s.d, t, out);
     else { V3 pos; hit = plane_test(a, b, c, e, s.o, s.d, t, pos); }
-    bvh_accept(hit, t, id, out, s.best, s.best_t, s.best_out);
+    bvh_accept(hit, t, id, out, slot, s.best, s.best_t, s.best_out, s.best_slot);
 }
 
 // One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of up to 128 bytes, then either the four
@@ -204,8 +208,8 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
     float4 q4 = q0, q5 = q0, q6 = q0, q7 = q0;
     if (second) { q4 = p[4]; q5 = p[5]; q6 = p[6]; if (in_leaf) q7 = p[7]; }
     if (in_leaf) {
-        bvh_test_record(sc, q0, q1, q2, q3, s);
-        if (second) bvh_test_record(sc, q4, q5, q6, q7, s);
+        bvh_test_record(sc, q0, q1, q2, q3, s.leaf_cur, s);
+        if (second) bvh_test_record(sc, q4, q5, q6, q7, s.leaf_cur + 1u, s);
         s.leaf_cur += second ? 2u : 1u;
         if (s.leaf_cur == s.leaf_end) trav_pop(s, stk);
         return second ? 2u : 1u;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #endif
                 my_steps += bvh_step(sc, st, stk);
                 if (st.node == BVH_EMPTY) {
-                    L.hitprim()[rec] = pack_hit(st.best, st.best_out);
+                    L.hitprim()[rec] = pack_hit(st.best == MISS ? MISS : st.best_slot, st.best_out);   // by shading row, not by id
                     L.hit_t()[rec] = st.best_t;
                     active = false;
                 }
@@ -370,6 +370,7 @@ __device__ __forceinline__ V3 child_radiance(const Level &L, const Level &Lup, u
 // needs no shadow ray (reference src/tracer.rs:472-476: Plane::sample said None, or there are no lights) is worth
 // zero, which is written into this node's val slot at once instead of queueing a record for k_terminal.
 // Every lane of the wave must call this (the append uses wave-wide ballots); `valid` masks padding lanes.
+template <bool ROWS = false>
 __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L, const Level &Lprev, const Level &Lnext, uint32_t level,
                                              uint32_t last_traced, uint32_t shard, bool valid, uint32_t i, V3 o, V3 d, uint32_t skey,
                                              uint32_t node, uint32_t prim, float hit_t, int hit_transition, Counters *ctr
@@ -384,7 +385,7 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
     c.n_children = 0;
     const uint32_t nkey = rng_node_key(skey, node);
     if (valid) {
-        shade_prepare(sc, o, d, prim, hit_t, hit_transition, nkey, c);
+        shade_prepare<ROWS>(sc, o, d, prim, hit_t, hit_transition, nkey, c);
     }
     bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
     bool folded = false;  // every child is a black terminal sample: the node's own radiance is known here and now
@@ -454,9 +455,10 @@ constexpr int LDS_SCENE_CAP = 1024;  // float4 rows: n_sph + 4 n_pl + 4 (n_sph +
 __host__ __device__ inline bool lds_scene_fits(uint32_t n_sph, uint32_t n_pl) { return 5ull * n_sph + 8ull * n_pl <= LDS_SCENE_CAP; }
 
 // Wave-granular kernel: each wave takes 64 consecutive records.  FUSED: intersection here as well; RAYGEN: level 0
-// generates its primary rays in place; LDS_SCENE: see above (the host checks lds_scene_fits).
+// generates its primary rays in place; LDS_SCENE: see above (the host checks lds_scene_fits).  BVH without FUSED: the
+// hits were left by k_trace_dyn, which names them by shading row (DevScene::shade_rows).
 template <bool FUSED, bool RAYGEN, bool LDS_SCENE, bool BVH>
-__global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
+__global__ __launch_bounds__(BLOCK, (BVH && FUSED) ? 4 : PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
     if (pass_voided(L)) return;
@@ -525,9 +527,9 @@ __global__ __launch_bounds__(BLOCK, BVH ? 4 : PT_SHADE_WAVES) void k_shade(DevSc
         }
         PT_STAMP(1);  // intersection
 #ifdef PT_STAMPS
-        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr, stamp_acc, stamp_last);
+        shade_record<(BVH && !FUSED)>(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr, stamp_acc, stamp_last);
 #else
-        shade_record(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr);
+        shade_record<(BVH && !FUSED)>(lsc, L, Lprev, Lnext, level, last_traced, shard, valid, i, o, d, skey, node, prim, hit_t, hit_tr, ctr);
 #endif
         PT_STAMP(6);  // child stores
         w = w_next; i = i_next; valid = valid_next; ra = ra_next; rb = rb_next;

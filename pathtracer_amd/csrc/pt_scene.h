@@ -41,6 +41,10 @@ struct DevScene {
     uint2 *bvh_spill;           // traversal stack entries beyond the LDS part (see pt_bvh.h)
     const uint32_t *bvh_always; // primitives that cannot be bounded: tested for every ray
     uint32_t n_always;
+    const float4 *shade_rows;   // [(leaf prims + n_always) * 4] what shading needs of a primitive, one 64-byte line each, in the order
+                                //   of bvh_geom (then the `always` list): (kind, color.xyz) (roughness, metalness, ior, bits(primitive id))
+                                //   (f0.xyz, 0) (plane normal or sphere centre .xyz, 0); the BVH trace kernel reports hits by this slot
+    uint32_t n_leaf_prims;      // slots of bvh_geom (the `always` primitives follow)
     // camera (reference src/tracer.rs:104-111: per-pixel step vectors of CameraSampler)
     V3 cam_origin, cam_su, cam_sv, cam_pos;
     int tone; float exposure; float iso_factor;
@@ -367,11 +371,33 @@ struct ShadeCtx {
 
 // `transition` < 0: only the primitive id is known, the Hit is rebuilt by re-running its test; otherwise (t,
 // transition) come from the nearest-hit search.
+// ROWS: `prim` is a slot of sc.shade_rows (what the BVH trace kernel reports) and everything shading needs of the
+// primitive comes from that one 64-byte line instead of from two tables indexed by primitive id; (t, transition) are
+// known.  PI * brdf_lambert(reflectivity) is then evaluated here with the operations the host uses for the table.
+template <bool ROWS = false>
 PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t prim, float t, int transition, uint32_t node_key, ShadeCtx &c) {
     c.n_children = 0;
     c.kind = NK_LEAF;
     bool hit = prim != MISS;
-    if (hit) {
+    float4 row2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ROWS) {
+        if (hit) {
+            const float4 *row = sc.shade_rows + 4 * (size_t)prim;
+            c.m0 = row[0];
+            c.m1 = row[1];
+            row2 = row[2];
+            float4 geo = row[3];
+            c.hit.t = t;
+            c.hit.position = origin + t * direction;
+            c.hit.transition = 0;
+            c.hit.normal = v3(geo.x, geo.y, geo.z);
+            if (f2u(c.m1.w) < sc.n_sph) {   // a sphere: geo is its centre (reference src/scene.rs:212,216)
+                V3 s = v3(geo.x, geo.y, geo.z);
+                c.hit.transition = transition;
+                c.hit.normal = transition == 0 ? normalize(c.hit.position - s) : normalize(s - c.hit.position);
+            }
+        }
+    } else if (hit) {
         if (transition >= 0) prim_hit_known(sc, prim, origin, direction, t, transition, c.hit);
         else hit = prim_hit(sc, prim, origin, direction, c.hit);
     }
@@ -381,8 +407,10 @@ PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t p
     }
     const float SHIFT_AMOUNT = 0.0001f;  // :495
     const float R = 0.04f;               // :499
-    c.m0 = sc.mat[4 * prim];
-    c.m1 = sc.mat[4 * prim + 1];
+    if (!ROWS) {
+        c.m0 = sc.mat[4 * prim];
+        c.m1 = sc.mat[4 * prim + 1];
+    }
     uint32_t mat = f2u(c.m0.x);
     V3 color = v3(c.m0.y, c.m0.z, c.m0.w);
     V3 outwards = c.hit.position + SHIFT_AMOUNT * c.hit.normal;
@@ -398,15 +426,18 @@ PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t p
         c.o1 = outwards;
         return;
     default: {                                               // MAT_PHYSICALLY, :537-569
-        float4 m2 = sc.mat[4 * prim + 2];
+        float4 m2 = ROWS ? row2 : sc.mat[4 * prim + 2];
         c.f0 = v3(m2.x, m2.y, m2.z);  // mix_vec3(0.04, reflectivity, metalness), :543: a constant of the material
         float a = random32(rng_draw(node_key, 2));
         uint32_t ch = rng_draw(node_key, 3) % 3u;
         float f0c = ch == 0 ? c.f0.x : (ch == 1 ? c.f0.y : c.f0.z);
         c.kind = a < f0c ? NK_SPECULAR : NK_DIFFUSE;
         c.n_children = 1;
-        float4 m3 = sc.mat[4 * prim + 3];
-        c.pi_lambert = v3(m3.x, m3.y, m3.z);
+        if (ROWS) c.pi_lambert = PI_F * (color / PI_F);   // PI * brdf_lambert(reflectivity), :334-337,567
+        else {
+            float4 m3 = sc.mat[4 * prim + 3];
+            c.pi_lambert = v3(m3.x, m3.y, m3.z);
+        }
         return;
     }
     }

@@ -63,7 +63,7 @@ struct PtHandle {
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
     float *d_sky = nullptr, *d_gamma = nullptr;
     BvhNode *d_bvh_nodes = nullptr;
-    float4 *d_bvh_geom = nullptr;
+    float4 *d_bvh_geom = nullptr, *d_shade_rows = nullptr;
     uint32_t *d_bvh_always = nullptr;
     uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
     uint64_t bvh_depth = 0, bvh_binary_depth = 0, bvh_forced_median_splits = 0, bvh_level_fold = 0;
@@ -183,7 +183,7 @@ void free_levels(PtHandle *h) {
 
 void free_scene(PtHandle *h) {
     dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
-    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always);
+    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always); dev_free(h->d_shade_rows);
     dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
     if (h->h_pixels8) { (void)hipHostFree(h->h_pixels8); h->h_pixels8 = nullptr; }
     free_levels(h);
@@ -480,7 +480,8 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
                 else k_trace<<<TG, BLOCK, lds, st>>>(sc, L);
             }
             Span s(h, PT_KERNEL_SHADE, st);
-            if (h->lds_scene) k_shade<false, false, true, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+            if (bvh) k_shade<false, false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);   // hits named by shading row
+            else if (h->lds_scene) k_shade<false, false, true, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
             else k_shade<false, false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         }
     }
@@ -804,6 +805,26 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
             HIPCHK(h, hipMemcpy(h->d_bvh_always, builder.always.data(), builder.always.size() * 4, hipMemcpyHostToDevice));
         sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_geom = h->d_bvh_geom;  // (the spill area belongs to the pipes)
         sc.bvh_always = h->d_bvh_always; sc.n_always = (uint32_t)builder.always.size();
+        {   // shading rows, in the order the trace kernel names hits: the leaves' primitives, then the `always` list
+            std::vector<uint32_t> order(builder.prims);
+            order.insert(order.end(), builder.always.begin(), builder.always.end());
+            std::vector<float4> rows(4 * std::max<size_t>(1, order.size()));
+            for (size_t k = 0; k < order.size(); ++k) {
+                const uint32_t id = order[k];
+                float4 m1 = mat[4 * (size_t)id + 1];
+                m1.w = u2f(id);
+                float4 geo = id < n_sph ? sph[id] : pln[4 * (size_t)(id - n_sph)];   // sphere centre / plane normal in .xyz
+                geo.w = 0.0f;
+                rows[4 * k] = mat[4 * (size_t)id];
+                rows[4 * k + 1] = m1;
+                rows[4 * k + 2] = mat[4 * (size_t)id + 2];
+                rows[4 * k + 3] = geo;
+            }
+            if ((rc = dev_alloc(h, &h->d_shade_rows, rows.size()))) return rc;
+            HIPCHK(h, hipMemcpy(h->d_shade_rows, rows.data(), rows.size() * sizeof(float4), hipMemcpyHostToDevice));
+            sc.shade_rows = h->d_shade_rows;
+            sc.n_leaf_prims = (uint32_t)builder.prims.size();
+        }
         h->bvh_nodes = builder.nodes.size(); h->bvh_leaf_prims = builder.prims.size();
         h->bvh_depth = (uint64_t)builder.depth4; h->bvh_binary_depth = (uint64_t)builder.max_depth_seen;
         h->bvh_forced_median_splits = builder.forced_median_splits; h->bvh_level_fold = builder.level_fold ? 1 : 0;
