@@ -137,9 +137,9 @@ def main() -> None:
     ap.add_argument("--accel", type=int, default=0, help="0 = library choice (BVH above 192 primitives), 1 = linear scan, 2 = BVH")
     ap.add_argument("--batch", type=int, default=0, help="samples per pixel per pipeline pass (0 = library default)")
     ap.add_argument("--passes", type=int, default=-1,
-                    help="pipeline passes in flight; 0 = library default (2); -1 = 1 for sample/room, so that the per-kernel "
-                         "durations of the roofline block are not blurred by a second pass running concurrently (the "
-                         "library default is measured by --pipelined), library default for quads")
+                    help="pipeline passes in flight; 0 = library default (2); -1 = 1, so that the per-kernel durations of the "
+                         "roofline block are not blurred by a second pass running concurrently (kernels of two passes that "
+                         "overlap each report the time they shared the GPU; the library default is measured by --pipelined)")
     ap.add_argument("--pipelined", action="store_true",
                     help="after the timed region, run the same steps again with the library's default of two passes in flight "
                          "(no per-kernel events) and report that throughput as `pipelined`")
@@ -184,7 +184,7 @@ def main() -> None:
     args.max_depth = depth
     args.spp_per_step = args.spp_per_step or (32 if args.workload == "quads" else 512)
     if args.passes < 0:
-        args.passes = 0 if args.workload == "quads" else 1
+        args.passes = 1
     cfg = dict(max_depth=args.max_depth, fuse_trace_shade=args.fused, samples_per_batch=args.batch, concurrent_passes=args.passes,
                accel=args.accel, profile_events=0 if args.no_events else 1)
 

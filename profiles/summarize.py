@@ -3,9 +3,12 @@ The output carries `_source_hash` (bench.py's hash over the device sources the r
 (git revision, handed in through PT_COMMIT: the GPU box has no .git), so that a reader - bench.py included - can
 tell whether the figures belong to the kernels it is looking at.
 
-FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-byte request of a wide coalesced
-read, i.e. half the bytes: it is doubled here (this pipeline reads 16 B per lane from consecutive records).
-WRITE_SIZE is exact for 16-byte-per-lane stores.  Output: <out>/<tag>_counters.json and <out>/<tag>_hbm_traffic.json
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-byte line requested from the memory
+side, whatever part of the line the wave reads: calibrated with profiles/micro/fetch_calibration.hip
+(profiles/r02_fetch_calibration.json) - a streamed 2 GiB table reads 0.500 of its bytes, and a gather of 16, 64 or
+112 bytes from each of 8M distinct lines reads 64.0 B per line in all three cases.  It is doubled here, which prices
+every touched line whole: exact for the streamed queue records, an upper bound for the BVH's per-lane node and leaf
+fetches.  WRITE_SIZE is exact for 16-byte-per-lane stores.  Output: <out>/<tag>_counters.json and <out>/<tag>_hbm_traffic.json
 (HBM bytes per launch per kernel class, the `traffic` field of bench.py's roofline block).
 """
 import collections
