@@ -33,16 +33,29 @@ def test_oracle_converges_to_the_published_render(oracle, mode):
     assert rmse < 8.5 and bias < 1.0 and median < 5.0 and outliers < 0.02, (rmse, bias, median, outliers)
     # and it is this scene, not just any grey box: the earlier revision docs/4.jpg (other caustic, darker walls) is further away
     rmse4, *_ = _errors(p8, np.load(FIX)["docs4"])
-    assert rmse4 > rmse + 3.0
+    rmse3, *_ = _errors(p8, np.load(FIX)["docs3"])   # docs/3.jpg: yet another revision (see make_docs_fixture.py)
+    assert rmse4 > rmse + 3.0 and rmse3 > rmse + 6.0, (rmse, rmse4, rmse3)
 
 
+# Measured on the GPU (profiles/debug/image_pin.py; the bounds below are 1.2x the 8192-spp figures):
+#   256x256:  2048 spp RMSE 4.95, 8192 spp 4.26, 32768 spp 4.06; bias 0.25, median per-pixel error 1.16, 0.46 % of pixels off by > 20
+#   512x512:  2048 spp RMSE 3.53, 8192 spp 2.48, 32768 spp 2.14; bias 0.07, median 1.41, 0.12 % of pixels off by > 20
+# (at 256 the residual is the 4x4 box filter of the fixture against one jittered ray footprint per pixel; at 512 what is
+# left is JPEG loss and the published image's own noise).  The per-channel bias bound is the sharp one: a render whose
+# overall energy is off by 0.1 % fails it.  Against docs/4.jpg and docs/3.jpg (earlier revisions of the reference) the
+# same render is 12.9 and 16.2 away.
 @pytest.mark.gpu
-def test_gpu_converges_to_the_published_render(binding):
-    ref = np.load(FIX)["docs5"]
-    sc = S.sample_scene(256, 256)
+@pytest.mark.parametrize("size, rmse_max, bias_max, median_max, outliers_max",
+                         [(256, 5.1, 0.30, 1.4, 0.0056), (512, 3.0, 0.085, 1.7, 0.0015)])
+def test_gpu_converges_to_the_published_render(binding, size, rmse_max, bias_max, median_max, outliers_max):
+    fix = np.load(os.path.join(os.path.dirname(FIX), f"reference_render_{size}.npz"))
+    sc = S.sample_scene(size, size)
     with binding.PtGpu() as gpu:
         gpu.upload_scene(sc)
         gpu.render(8192)
         p8 = gpu.read_pixels8()
-    rmse, bias, median, outliers = _errors(p8, ref)
-    assert rmse < 6.0 and bias < 1.0 and median < 3.0 and outliers < 0.02, (rmse, bias, median, outliers)
+    rmse, bias, median, outliers = _errors(p8, fix["docs5"])
+    got = f"{size}x{size} at 8192 spp: RMSE {rmse:.3f} (max {rmse_max}), bias {bias:.3f} ({bias_max}), median {median:.3f} ({median_max}), outliers {outliers:.4f} ({outliers_max})"
+    assert rmse < rmse_max and bias < bias_max and median < median_max and outliers < outliers_max, got
+    if size == 256:   # and it is the current revision's image: the earlier ones are far away
+        assert _errors(p8, fix["docs4"])[0] > rmse + 6.0 and _errors(p8, fix["docs3"])[0] > rmse + 9.0, got
