@@ -244,6 +244,22 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
     return 2u;
 }
 
+// Is the terminal light sample at distance `light_distance` along (o, d) lit?  The reference asks for the NEAREST hit and
+// then tests `hit.t > light_distance - 1e-6` (src/tracer.rs:482-488; no hit at all: black).  The nearest distance is at
+// most any accepted distance, so the first accepted hit at or below that limit already decides "black" and the walk
+// stops there; otherwise it runs to the end and the answer is "some primitive was hit" (all of them beyond the limit).
+__device__ __forceinline__ bool bvh_light_visible(const DevScene &sc, V3 o, V3 d, float light_distance) {
+    const float limit = light_distance - 0.000001f;
+    Trav s;
+    bvh_begin(sc, o, d, s);
+    TravStack stk = trav_stack(sc);
+    while (s.node != BVH_EMPTY) {
+        if (s.best_t <= limit) return false;
+        (void)bvh_step(sc, s, stk);
+    }
+    return s.best != MISS && s.best_t > limit;
+}
+
 __device__ __forceinline__ uint32_t bvh_nearest(const DevScene &sc, V3 o, V3 d, float &best_t, int &best_out) {
     Trav s;
     bvh_begin(sc, o, d, s);

@@ -804,9 +804,13 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
             float dist;
             shadow = terminal_sample(sc, o, nkey, dir, dist, radiance);
             if (shadow) {
-                float t;
-                uint32_t prim = nearest_hit<BVH>(sc, o, dir, t);
-                if (prim != MISS && t > dist - 0.000001f) value = radiance;
+                if (BVH) {
+                    if (bvh_light_visible(sc, o, dir, dist)) value = radiance;   // stops at the first occluder
+                } else {
+                    float t;
+                    uint32_t prim = nearest_hit<false>(sc, o, dir, t);
+                    if (prim != MISS && t > dist - 0.000001f) value = radiance;
+                }
             }
             uint32_t par = L.parent()[i];
             float4 v = make_float4(value.x, value.y, value.z, 0.0f);
