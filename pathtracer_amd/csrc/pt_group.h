@@ -49,6 +49,7 @@ struct PtGroup {
     uint64_t total_samples = 0;   // what the last reduction summed
     uint64_t exchange_bytes = 0;
     double exchange_ms = 0.0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // around the reduction on devices[0]'s stream (created at the first one)
 };
 
 namespace {
@@ -115,6 +116,14 @@ void group_free_buffers(PtGroup *g) {
     g->d_sum = nullptr; g->d_pixels8 = nullptr; g->h_pixels8 = nullptr;
 }
 
+void group_free_events(PtGroup *g) {
+    if (g->devices.empty()) return;
+    (void)hipSetDevice(g->devices[0]);
+    if (g->t0) (void)hipEventDestroy(g->t0);
+    if (g->t1) (void)hipEventDestroy(g->t1);
+    g->t0 = g->t1 = nullptr;
+}
+
 // samples with global index below c that belong to device k of n
 inline uint64_t shard_count_below(uint64_t c, uint32_t k, uint32_t n) { return (c + n - 1 - k) / n; }
 
@@ -144,26 +153,23 @@ int group_reduce(PtGroup *g) {
         g->comms_ready = true;
     }
     GHIPCHK(g, hipSetDevice(g->devices[0]));
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    GHIPCHK(g, hipEventCreate(&t0));
-    GHIPCHK(g, hipEventCreate(&t1));
-    GHIPCHK(g, hipEventRecord(t0, g->members[0]->stream));
+    if (!g->t0) GHIPCHK(g, hipEventCreate(&g->t0));
+    if (!g->t1) GHIPCHK(g, hipEventCreate(&g->t1));
+    GHIPCHK(g, hipEventRecord(g->t0, g->members[0]->stream));
     NCCLCHK(g, ncclGroupStart());
     for (uint32_t k = 0; k < n; ++k) {
         ncclResult_t r = ncclReduce(g->members[k]->d_pixels32, g->d_sum, words, ncclUint32, ncclSum, 0, g->comms[k], g->members[k]->stream);
         if (r != ncclSuccess) {
             (void)ncclGroupEnd();
-            (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
             return group_fail(g, PT_ERR_HIP, std::string("ncclReduce: ") + ncclGetErrorString(r));
         }
     }
     NCCLCHK(g, ncclGroupEnd());
     GHIPCHK(g, hipSetDevice(g->devices[0]));
-    GHIPCHK(g, hipEventRecord(t1, g->members[0]->stream));
+    GHIPCHK(g, hipEventRecord(g->t1, g->members[0]->stream));
     for (uint32_t k = 0; k < n; ++k) GHIPCHK(g, hipStreamSynchronize(g->members[k]->stream));
     float ms = 0.0f;
-    (void)hipEventElapsedTime(&ms, t0, t1);
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    (void)hipEventElapsedTime(&ms, g->t0, g->t1);
     g->exchange_ms = ms;
     g->exchange_bytes = words * 4;
     uint64_t total = 0;
@@ -228,6 +234,7 @@ void ptgpu_group_destroy(PtGroup *g) {
     for (PtHandle *h : g->members) if (h) { (void)hipSetDevice(h->device); (void)ptgpu_sync(h); }
     if (g->comms_ready) for (ncclComm_t c : g->comms) if (c) (void)ncclCommDestroy(c);
     group_free_buffers(g);
+    group_free_events(g);
     for (PtHandle *h : g->members) ptgpu_destroy(h);
     delete g;
 }

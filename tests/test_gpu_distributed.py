@@ -29,3 +29,15 @@ def test_bench_under_torchrun_with_nccl_collective():
     assert d["n_gpus"] == 1 and d["config"]["accumulated_spp"] == 2 * d["config"]["spp_per_step"] and d["value"] > 0
     assert d["roofline"]["kernel"] == "trace_shade" and 0 < d["roofline"]["frac"] < 1
     assert d["exchange"]["bytes"] == 640 * 360 * 12 and d["exchange"]["ms"] > 0
+
+
+def test_bench_inproc_group():
+    """bench.py --inproc: the same JSON shape with the GPUs driven from one process through the library's PtGroup."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--inproc", "--steps", "2", "--warmup", "1", "--spp-per-step", "8",
+           "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["accumulated_spp"] == 16 and d["value"] > 0 and "PtGroup" in d["config"]["parallelism"]
+    assert d["roofline"]["kernel"] == "trace_shade" and 0 < d["roofline"]["frac"] < 1
+    assert d["exchange"]["bytes"] == 640 * 360 * 12 and d["exchange"]["ms"] > 0 and d["exchange"]["device_ms"] >= 0
