@@ -33,7 +33,7 @@ def source_hash() -> str:
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "pathtracer_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip")):
+        if f.endswith((".h", ".hip")) and f != "pt_group.h":   # (pt_group.h is host code only: no kernel depends on it)
             h.update(f.encode())
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]

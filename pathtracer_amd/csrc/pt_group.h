@@ -285,7 +285,13 @@ int ptgpu_group_render(PtGroup *g, uint32_t n_samples) {
         const uint64_t mine = ptgpu_group_shard_samples(c0, c1 - c0, k, n);
         return mine ? ptgpu_render(g->members[k], (uint32_t)mine) : (int)PT_OK;
     });
-    if (rc) return rc;
+    if (rc) {
+        // some devices may have enqueued their share and others not: the accumulators no longer add up to a contiguous
+        // range of sample indices, so the group refuses further work until the scene is uploaded again
+        g->have_scene = false;
+        g->error += " (ptgpu_group_render failed part-way: upload the scene again)";
+        return rc;
+    }
     g->cursor = c1;
     return PT_OK;
     PT_API_END(nullptr)
