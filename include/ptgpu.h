@@ -104,7 +104,7 @@ typedef struct {
     uint32_t shard_count;
     uint32_t samples_per_batch;   /* samples per pixel traced per pipeline pass; 0 = auto */
     uint32_t branch_capacity;     /* queue level l holds min(2^l, branch_capacity) x batch records and an overflow is
-                                     PT_ERR_QUEUE_OVERFLOW; 0 = start at 2 and grow: a pass that overflows adds nothing and is
+                                     PT_ERR_QUEUE_OVERFLOW; 0 = start at 1 and grow: a pass that overflows adds nothing and is
                                      rendered again, with the levels re-allocated twice as large, at the next synchronisation */
     int32_t accel;                /* PT_ACCEL_* */
     int32_t fuse_trace_shade;     /* 0: trace and shade kernels; 1: one fused kernel per level; 2: fused, and each block regroups
