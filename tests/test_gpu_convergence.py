@@ -113,3 +113,46 @@ def test_full_size_pixels_bit_exact(binding, oracle, width, height, spp):
     r32, r8, rays = oracle.OracleScene(sc).render(oracle.options(oracle.RNG_COUNTER, oracle.MATH_DET), spp, threads=16)
     assert n == spp and st["rays"] == rays
     assert np.array_equal(p32, r32) and np.array_equal(p8, r8)
+
+
+def test_full_size_room_depth_16_bit_exact(binding, oracle):
+    """The queue-compaction configuration at its own size: the closed diffuse room, 1920x1080, max_depth 16, against the
+    oracle's worker pool pixel for pixel (one sample per pixel: 17 levels of records, a shrinking share of the paths
+    ending on the light at every level)."""
+    sc = S.diffuse_room_scene(1920, 1080)
+    with binding.PtGpu(max_depth=16) as gpu:
+        gpu.upload_scene(sc)
+        gpu.render(1)
+        p32, n = gpu.read_pixels32()
+        st = gpu.stats()
+    r32, _, rays = oracle.OracleScene(sc).render(oracle.options(max_depth=16), 1, threads=16)
+    assert n == 1 and st["rays"] == rays and np.array_equal(p32, r32)
+    occ = [x / (1920 * 1080) for x in st["level_records"][:17]]
+    assert occ[0] == 1.0 and all(occ[k + 1] <= occ[k] for k in range(15)) and occ[15] > 0.8   # most paths live all 16 levels
+
+
+def test_full_size_2160p_eight_shards_sum_to_one_gpu(binding):
+    """The 3840x2160 configuration's gate, with the eight GPUs replayed one after the other on this one: shard k of 8
+    renders the sample indices the group's split rule gives it, and the sum of the eight accumulators (what the RCCL
+    reduction computes) is the single-GPU accumulator for the same 16 samples, bit for bit."""
+    lib = binding.load_library()
+    sc = S.sample_scene(3840, 2160, camera_width=8.8888889)
+    with binding.PtGpu() as one:
+        one.upload_scene(sc)
+        one.render(16)
+        ref, n_ref = one.read_pixels32()
+    total = np.zeros_like(ref)
+    n_total = 0
+    for k in range(8):
+        with binding.PtGpu(shard_index=k, shard_count=8) as gpu:
+            gpu.upload_scene(sc)
+            first = 0
+            for call in (5, 11):
+                mine = lib.ptgpu_group_shard_samples(first, call, k, 8)
+                if mine:
+                    gpu.render(mine)
+                first += call
+            p32, n = gpu.read_pixels32()
+        total += p32
+        n_total += n
+    assert n_total == n_ref == 16 and np.array_equal(total, ref)
