@@ -57,11 +57,50 @@ struct BvhBuilder {
 
     static bool finite3(double a, double b, double c) { return std::isfinite(a) && std::isfinite(b) && std::isfinite(c); }
 
+    // The padded box of everything the tree holds: a ray that misses it misses every primitive - provided nothing is
+    // on the `always` list.  Call after boxes().  False: no usable bound (unboundable primitives, or nothing at all).
+    bool scene_bounds(float lo[3], float hi[3]) const {
+        if (!always.empty() || idx.empty()) return false;
+        Box b; b.reset();
+        for (uint32_t i : idx) b.grow(pbox[i]);
+        for (int d = 0; d < 3; ++d) { lo[d] = down(b.lo[d] - pad); hi[d] = up(b.hi[d] + pad); }
+        return true;
+    }
+
     void build(const std::vector<float4> &sph, const std::vector<float4> &pln, V3 cam_pos, V3 cam_plane_origin) {
+        boxes(sph, pln, cam_pos, cam_plane_origin);
+        nodes.clear();
+        prims.clear();
+        bn.clear();
+        if (idx.empty()) {  // nothing boundable: a root with two empty children
+            BvhNode root{};
+            root.c[0] = root.c[1] = root.c[2] = root.c[3] = BVH_EMPTY;
+            nodes.push_back(root);
+            return;
+        }
+        bn.reserve(idx.size());
+        max_depth_seen = 0;
+        forced_median_splits = 0;
+        build_range(0, (uint32_t)idx.size(), 0);
+        // The traversal pushes up to three children per inner node on the way down, so its stack holds at most
+        // 3 * depth4 entries.  Folding by box area (fastest to traverse) gives no bound better than the binary depth
+        // cap; when such a tree would be too deep for the stack it is folded again level by level, which halves the
+        // binary depth: at most (BVH_BINARY_DEPTH + 1) / 2 = 19 levels, 57 entries.
+        level_fold = false;
+        flatten();
+        if (3 * depth4 > BVH_STACK) {
+            level_fold = true;
+            flatten();
+        }
+    }
+
+    // Per-primitive boxes (pbox, idx), the `always` list and the padding.
+    void boxes(const std::vector<float4> &sph, const std::vector<float4> &pln, V3 cam_pos, V3 cam_plane_origin) {
         const uint32_t n_sph = (uint32_t)sph.size(), n_pl = (uint32_t)(pln.size() / 4);
         const uint32_t n = n_sph + n_pl;
         src_sph = &sph; src_pln = &pln;
         geom.clear();
+        always.clear();
         pbox.resize(n);
         pcent.resize(3 * (size_t)n);
         idx.clear();
@@ -112,30 +151,6 @@ struct BvhBuilder {
         }
         pad = std::ldexp(std::max(M, 1e-30), -16);
         std::sort(always.begin(), always.end());
-
-        nodes.clear();
-        prims.clear();
-        bn.clear();
-        if (idx.empty()) {  // nothing boundable: a root with two empty children
-            BvhNode root{};
-            root.c[0] = root.c[1] = root.c[2] = root.c[3] = BVH_EMPTY;
-            nodes.push_back(root);
-            return;
-        }
-        bn.reserve(idx.size());
-        max_depth_seen = 0;
-        forced_median_splits = 0;
-        build_range(0, (uint32_t)idx.size(), 0);
-        // The traversal pushes up to three children per inner node on the way down, so its stack holds at most
-        // 3 * depth4 entries.  Folding by box area (fastest to traverse) gives no bound better than the binary depth
-        // cap; when such a tree would be too deep for the stack it is folded again level by level, which halves the
-        // binary depth: at most (BVH_BINARY_DEPTH + 1) / 2 = 19 levels, 57 entries.
-        level_fold = false;
-        flatten();
-        if (3 * depth4 > BVH_STACK) {
-            level_fold = true;
-            flatten();
-        }
     }
 
     Box range_box(uint32_t first, uint32_t count) const {

@@ -180,6 +180,24 @@ __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, 
     return nearest_hit<BVH>(sc, o, d, t, transition);
 }
 
+// Can the ray reach the box [lo, hi] at all?  Conservative on purpose: approximate reciprocals, the far distance widened,
+// every comparison written so that a NaN says "maybe".  The box is the BVH builder's (the region in which the
+// reference's own tests can accept a hit, padded by 2^-16 of the scene's size), so "no" means that no primitive test can
+// succeed (reference src/scene.rs:263-297 would return None) and the scan over the primitives can be skipped.
+__device__ __forceinline__ bool may_reach_box(V3 lo, V3 hi, V3 o, V3 d) {
+    const float big = 1e30f;
+    float ix = __builtin_fabsf(d.x) > 1e-30f ? __builtin_amdgcn_rcpf(d.x) : __builtin_copysignf(big, d.x);
+    float iy = __builtin_fabsf(d.y) > 1e-30f ? __builtin_amdgcn_rcpf(d.y) : __builtin_copysignf(big, d.y);
+    float iz = __builtin_fabsf(d.z) > 1e-30f ? __builtin_amdgcn_rcpf(d.z) : __builtin_copysignf(big, d.z);
+    float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
+    float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
+    float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));   // (fminf/fmaxf drop a NaN operand)
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    tf = tf * 1.0001f + 1e-4f;
+    return !(tn > tf) && !(tf < 0.0f);
+}
+
 // ---- raygen: reference src/tracer.rs:125-142,628-631 -------------------------------------------------------
 // A ray record carries the sample's RNG key (not the sample id), so no level has to redo the pixel/sample split.
 __device__ __forceinline__ void primary_ray(const DevScene &sc, const PassParams &pp, uint32_t sid, V3 &o, V3 &d, uint32_t &skey) {
@@ -517,8 +535,11 @@ __global__ __launch_bounds__(BLOCK, (BVH && FUSED) ? 4 : PT_SHADE_WAVES) void k_
         }
         PT_STAMP(0);  // tile bookkeeping + ray fetch
         if (valid) {
-            if (FUSED) prim = nearest_hit<BVH>(sc, o, d, hit_t, hit_tr);
-            else {  // the trace kernel left the winner, its Transition and its distance
+            // primary rays of a linear-scan scene: a wave none of whose rays can reach the scene's box skips the scan
+            const bool reach = !(RAYGEN && !BVH) || !sc.has_bounds || may_reach_box(sc.bounds_lo, sc.bounds_hi, o, d);
+            if (FUSED) {
+                if (!(RAYGEN && !BVH) || __ballot(reach) != 0ull) prim = nearest_hit<BVH>(sc, o, d, hit_t, hit_tr);
+            } else {  // the trace kernel left the winner, its Transition and its distance
                 uint32_t word = L.hitprim()[i];
                 hit_t = L.hit_t()[i];
                 prim = word == MISS ? MISS : (word & ~HIT_OUT_BIT);

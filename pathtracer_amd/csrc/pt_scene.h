@@ -49,6 +49,8 @@ struct DevScene {
     V3 cam_origin, cam_su, cam_sv, cam_pos;
     int tone; float exposure; float iso_factor;
     int sky_kind; V3 sky_radiance; const float *sky_pixels; uint32_t sky_w, sky_h;
+    int has_bounds;                // bounds_lo/hi hold the padded box of all primitives (linear-scan scenes): a primary ray that
+    V3 bounds_lo, bounds_hi;       // misses it misses everything
     const float *gamma_table;  // [256] smallest x with trunc(255 * x^(1/2.2)) >= k (see gamma_quantise); may be null
     uint32_t width, height;
     int jitter;

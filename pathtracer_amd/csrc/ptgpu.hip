@@ -830,6 +830,16 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
         h->bvh_forced_median_splits = builder.forced_median_splits; h->bvh_level_fold = builder.level_fold ? 1 : 0;
         h->lds_bytes = (size_t)BVH_LDS_ENTRIES * BVH_STACK_STRIDE * sizeof(uint2);
     }
+    if (sc.bvh_nodes == nullptr && n_sph + n_pl > 0) {   // linear scan: the box of everything, for the primary rays' early out
+        BvhBuilder bounds;
+        bounds.boxes(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
+        float lo[3], hi[3];
+        if (bounds.scene_bounds(lo, hi)) {
+            sc.has_bounds = 1;
+            sc.bounds_lo = v3(lo[0], lo[1], lo[2]);
+            sc.bounds_hi = v3(hi[0], hi[1], hi[2]);
+        }
+    }
     // auto: BVH scenes run intersection as its own kernel (dynamic ray fetch), small scenes fuse it with shading
     h->fused = h->cfg.fuse_trace_shade < 0 ? (sc.bvh_nodes == nullptr) : (h->cfg.fuse_trace_shade != 0);
     h->lds_scene = sc.bvh_nodes == nullptr && lds_scene_fits(sc.n_sph, sc.n_pl);

@@ -403,6 +403,31 @@ def test_axis_aligned_rectangles_short_test(binding, oracle):
         assert np.array_equal(ids, osc.primary_ids(oracle.options(sub_pixel_override=jitter), 1))
 
 
+# ---- primary rays that cannot reach the scene's bounding box skip the scan ------------------------------------------
+@pytest.mark.parametrize("jitter", [0, 1])
+def test_silhouettes_on_the_faces_of_the_scene_box(binding, oracle, jitter):
+    """Open scenes whose outline IS their bounding box: a lone sphere (every silhouette ray grazes a face of the box), a
+    rectangle seen edge-on through the image centre, and a camera looking along an axis, so that with jitter off a whole
+    image column and row have an exactly zero direction component.  Most of the image sees the sky."""
+    gold = S.Material.physically((1.0, 0.8, 0.4), 0.2, 1.0)
+    grey = S.Material.physically((0.8, 0.8, 0.8), 0.9, 0.0)
+    for prims in ([S.Sphere((0.0, 0.0, 0.0), 1.0, gold)],
+                  [S.Plane((-1.0, 0.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), grey)],   # y = 0: edge-on for the centre row
+                  [S.Sphere((-2.0, 0.5, 0.0), 0.5, S.Material.translucent(1.5)), S.Sphere((1.5, -0.25, 1.0), 0.75, gold),
+                   S.Plane((-3.0, -1.0, -1.0), (6.0, 0.0, 0.0), (0.0, 0.0, 3.0), grey),
+                   S.Plane((-0.5, 2.0, -0.5), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0), S.Material.emissive((9.0, 9.0, 9.0)))]):
+        sc = S.Scene(
+            image_settings=S.ImageSettings(129, 97, bool(jitter)),
+            camera=S.Camera((0.0, 0.0, 8.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 8.0, 6.0, 4.0, S.TONE_CLAMP, 1.0, 100.0),
+            sky=S.Sky.constant((0.3, 0.4, 0.5)),
+        )
+        for p in prims:
+            sc.add(p)
+        p32, p8, ns, st = _gpu_render(binding, sc, 6)
+        _, _, (r32, r8, rays) = _oracle_render(oracle, sc, 6)
+        assert np.array_equal(p32, r32) and np.array_equal(p8, r8) and st["rays"] == rays, len(prims)
+
+
 def test_present_gives_the_display_bytes(binding):
     """The window loop's per-frame readback (Backbuffer.pixels8, src/window.rs:205-210) through the library's own
     page-locked buffer: the same bytes as ptgpu_read_pixels8, frame after frame and after a new scene of another size."""
