@@ -114,10 +114,18 @@ __device__ __forceinline__ void bvh_test_prims(const DevScene &sc, const uint32_
 // BVH_LDS_ENTRIES * 256 * 8 bytes of dynamic LDS.
 extern __shared__ uint2 pt_lds_stack[];
 
+// An entry as one 64-bit word: child reference in the low half, entry distance (f32 bits) in the high half.  The LDS
+// part is addressed through a pointer that names its address space, so that its accesses stay LDS instructions: with
+// two generic pointers the compiler merges the two arms of put/get into one flat access through a selected pointer.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+__device__ __forceinline__ unsigned long long stack_entry(int32_t ref, float dist) {
+    return (unsigned long long)(uint32_t)ref | ((unsigned long long)__float_as_uint(dist) << 32);
+}
+
 struct TravStack {
-    uint2 *lds;     // pt_lds_stack + threadIdx.x
-    uint2 *spill;   // sc.bvh_spill + global thread index
-    __device__ __forceinline__ void put(int k, uint2 e) const {
+    lds_u64 *lds;                // pt_lds_stack + threadIdx.x
+    unsigned long long *spill;   // sc.bvh_spill + global thread index
+    __device__ __forceinline__ void put(int k, unsigned long long e) const {
         if (k < BVH_LDS_ENTRIES) lds[k * BVH_STACK_STRIDE] = e;
         else {
             // the builder bounds the depth so that k < BVH_STACK always; the clamp keeps a tree that broke that promise
@@ -126,7 +134,7 @@ struct TravStack {
             spill[(size_t)(k - BVH_LDS_ENTRIES) * (BVH_TRAV_BLOCKS * BVH_STACK_STRIDE)] = e;
         }
     }
-    __device__ __forceinline__ uint2 get(int k) const {
+    __device__ __forceinline__ unsigned long long get(int k) const {
         if (k < BVH_LDS_ENTRIES) return lds[k * BVH_STACK_STRIDE];
         k = k < BVH_STACK ? k : BVH_STACK - 1;
         return spill[(size_t)(k - BVH_LDS_ENTRIES) * (BVH_TRAV_BLOCKS * BVH_STACK_STRIDE)];
@@ -134,8 +142,8 @@ struct TravStack {
 };
 __device__ __forceinline__ TravStack trav_stack(const DevScene &sc) {
     TravStack s;
-    s.lds = pt_lds_stack + threadIdx.x;
-    s.spill = sc.bvh_spill + ((size_t)blockIdx.x * BVH_STACK_STRIDE + threadIdx.x);
+    s.lds = (lds_u64 *)pt_lds_stack + threadIdx.x;
+    s.spill = reinterpret_cast<unsigned long long *>(sc.bvh_spill) + ((size_t)blockIdx.x * BVH_STACK_STRIDE + threadIdx.x);
     return s;
 }
 
@@ -167,8 +175,8 @@ __device__ __forceinline__ void trav_pop(Trav &s, const TravStack &stk) {
     for (;;) {
         if (s.sp == 0) { s.node = BVH_EMPTY; return; }
         --s.sp;
-        uint2 e = stk.get(s.sp);
-        if (__uint_as_float(e.y) <= s.best_t) { trav_enter(s, (int32_t)e.x); return; }
+        unsigned long long e = stk.get(s.sp);
+        if (__uint_as_float((uint32_t)(e >> 32)) <= s.best_t) { trav_enter(s, (int32_t)(uint32_t)e); return; }
     }
 }
 
@@ -207,41 +215,60 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
     float4 q4 = q0, q5 = q0, q6 = q0, q7 = q0;
     if (second) { q4 = p[4]; q5 = p[5]; q6 = p[6]; if (in_leaf) q7 = p[7]; }
+    bool pop;            // this subtree is done: take the next one from the stack (one site for both kinds of step)
+    uint32_t units = 2u;
     if (in_leaf) {
         bvh_test_record(sc, q0, q1, q2, q3, s.leaf_cur, s);
         if (second) bvh_test_record(sc, q4, q5, q6, q7, s.leaf_cur + 1u, s);
         s.leaf_cur += second ? 2u : 1u;
-        if (s.leaf_cur == s.leaf_end) trav_pop(s, stk);
-        return second ? 2u : 1u;
+        pop = s.leaf_cur == s.leaf_end;
+        units = second ? 2u : 1u;
+    } else {
+        // q0..q5 = lox, loy, loz, hix, hiy, hiz of the four children; q6 = their references
+        f32x2 tnA, tfA, tnB, tfB;
+        box_entry2(f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, f32x2{q3.x, q3.y}, f32x2{q4.x, q4.y}, f32x2{q5.x, q5.y}, s.inv,
+                   s.noi, tnA, tfA);
+        box_entry2(f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, f32x2{q3.z, q3.w}, f32x2{q4.z, q4.w}, f32x2{q5.z, q5.w}, s.inv,
+                   s.noi, tnB, tfB);
+        const int32_t c0 = (int32_t)__float_as_uint(q6.x), c1 = (int32_t)__float_as_uint(q6.y);
+        const int32_t c2 = (int32_t)__float_as_uint(q6.z), c3 = (int32_t)__float_as_uint(q6.w);
+        const float INF = __builtin_inff();
+        // key = entry distance of a child the ray must visit, +inf otherwise
+        float k0 = (c0 != BVH_EMPTY && tnA.x <= tfA.x && tnA.x <= s.best_t) ? tnA.x : INF;
+        float k1 = (c1 != BVH_EMPTY && tnA.y <= tfA.y && tnA.y <= s.best_t) ? tnA.y : INF;
+        float k2 = (c2 != BVH_EMPTY && tnB.x <= tfB.x && tnB.x <= s.best_t) ? tnB.x : INF;
+        float k3 = (c3 != BVH_EMPTY && tnB.y <= tfB.y && tnB.y <= s.best_t) ? tnB.y : INF;
+        // (a child entered at distance +inf cannot hold a finite hit, so treating it as missed loses nothing)
+        int j = 0;
+        float kj = k0;
+        if (k1 < kj) { kj = k1; j = 1; }
+        if (k2 < kj) { kj = k2; j = 2; }
+        if (k3 < kj) { kj = k3; j = 3; }
+        pop = kj == INF;
+        if (!pop) {
+            // the others in fixed order; entries are culled by distance again when they are popped
+            const bool p3 = j != 3 && k3 < INF, p2 = j != 2 && k2 < INF, p1 = j != 1 && k1 < INF, p0 = j != 0 && k0 < INF;
+            const unsigned long long e3 = stack_entry(c3, k3), e2 = stack_entry(c2, k2), e1 = stack_entry(c1, k1), e0 = stack_entry(c0, k0);
+            if (s.sp <= BVH_LDS_ENTRIES - 4) {
+                // all four written one after the other, each over its predecessor when that one is not kept: no branches,
+                // and the slots touched (sp .. sp + 3; child j is never kept) are all in LDS
+                lds_u64 *w = stk.lds + s.sp * BVH_STACK_STRIDE;
+                *w = e3; w += p3 ? BVH_STACK_STRIDE : 0;
+                *w = e2; w += p2 ? BVH_STACK_STRIDE : 0;
+                *w = e1; w += p1 ? BVH_STACK_STRIDE : 0;
+                *w = e0;
+                s.sp += (int)p3 + (int)p2 + (int)p1 + (int)p0;
+            } else {
+                if (p3) { stk.put(s.sp, e3); ++s.sp; }
+                if (p2) { stk.put(s.sp, e2); ++s.sp; }
+                if (p1) { stk.put(s.sp, e1); ++s.sp; }
+                if (p0) { stk.put(s.sp, e0); ++s.sp; }
+            }
+            trav_enter(s, j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3)));
+        }
     }
-    // q0..q5 = lox, loy, loz, hix, hiy, hiz of the four children; q6 = their references
-    f32x2 tnA, tfA, tnB, tfB;
-    box_entry2(f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, f32x2{q3.x, q3.y}, f32x2{q4.x, q4.y}, f32x2{q5.x, q5.y}, s.inv, s.noi,
-               tnA, tfA);
-    box_entry2(f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, f32x2{q3.z, q3.w}, f32x2{q4.z, q4.w}, f32x2{q5.z, q5.w}, s.inv, s.noi,
-               tnB, tfB);
-    const int32_t c0 = (int32_t)__float_as_uint(q6.x), c1 = (int32_t)__float_as_uint(q6.y);
-    const int32_t c2 = (int32_t)__float_as_uint(q6.z), c3 = (int32_t)__float_as_uint(q6.w);
-    const float INF = __builtin_inff();
-    // key = entry distance of a child the ray must visit, +inf otherwise
-    float k0 = (c0 != BVH_EMPTY && tnA.x <= tfA.x && tnA.x <= s.best_t) ? tnA.x : INF;
-    float k1 = (c1 != BVH_EMPTY && tnA.y <= tfA.y && tnA.y <= s.best_t) ? tnA.y : INF;
-    float k2 = (c2 != BVH_EMPTY && tnB.x <= tfB.x && tnB.x <= s.best_t) ? tnB.x : INF;
-    float k3 = (c3 != BVH_EMPTY && tnB.y <= tfB.y && tnB.y <= s.best_t) ? tnB.y : INF;
-    // (a child entered at distance +inf cannot hold a finite hit, so treating it as missed loses nothing)
-    int j = 0;
-    float kj = k0;
-    if (k1 < kj) { kj = k1; j = 1; }
-    if (k2 < kj) { kj = k2; j = 2; }
-    if (k3 < kj) { kj = k3; j = 3; }
-    if (kj == INF) { trav_pop(s, stk); return 2u; }
-    // the others in fixed order; entries are culled by distance again when they are popped
-    if (j != 3 && k3 < INF) { stk.put(s.sp, make_uint2((uint32_t)c3, __float_as_uint(k3))); ++s.sp; }
-    if (j != 2 && k2 < INF) { stk.put(s.sp, make_uint2((uint32_t)c2, __float_as_uint(k2))); ++s.sp; }
-    if (j != 1 && k1 < INF) { stk.put(s.sp, make_uint2((uint32_t)c1, __float_as_uint(k1))); ++s.sp; }
-    if (j != 0 && k0 < INF) { stk.put(s.sp, make_uint2((uint32_t)c0, __float_as_uint(k0))); ++s.sp; }
-    trav_enter(s, j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3)));
-    return 2u;
+    if (pop) trav_pop(s, stk);
+    return units;
 }
 
 // Is the terminal light sample at distance `light_distance` along (o, d) lit?  The reference asks for the NEAREST hit and
