@@ -165,7 +165,7 @@ __device__ __forceinline__ void trav_enter(Trav &s, int32_t ref) {
     if (ref < 0) {
         uint32_t payload = (uint32_t)~ref;
         s.leaf_cur = payload >> 3;
-        s.leaf_end = s.leaf_cur + (payload & 7u) + 1u;
+        if (BVH_MAX_LEAF > 1) s.leaf_end = s.leaf_cur + (payload & 7u) + 1u;
     }
 }
 
@@ -211,19 +211,18 @@ __device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, fl
 __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk) {
     const bool in_leaf = s.node < 0;
     const float4 *p = in_leaf ? sc.bvh_geom + 4 * (size_t)s.leaf_cur : reinterpret_cast<const float4 *>(sc.bvh_nodes + s.node);
-    const bool second = !in_leaf || s.leaf_cur + 1u < s.leaf_end;  // an inner node, or a leaf with two primitives left
+    // the second half of the line: an inner node's upper corners and references, or a leaf's second primitive
+    const bool second = !in_leaf || (BVH_MAX_LEAF > 1 && s.leaf_cur + 1u < s.leaf_end);
     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    float4 q4 = q0, q5 = q0, q6 = q0, q7 = q0;
-    if (second) { q4 = p[4]; q5 = p[5]; q6 = p[6]; if (in_leaf) q7 = p[7]; }
-    bool pop;            // this subtree is done: take the next one from the stack (one site for both kinds of step)
+    float4 q4, q5, q6, q7;
+    if (second) { q4 = p[4]; q5 = p[5]; q6 = p[6]; if (BVH_MAX_LEAF > 1 && in_leaf) q7 = p[7]; }
+    // All of the line is requested here, in one round trip.  Without this (empty) statement that names the second half,
+    // the compiler moves those loads down into the inner-node arm, behind the primitive test of the lanes that are in a
+    // leaf: a second round trip per step for every lane of the wave.
+    asm volatile("" : "+v"(q4.x), "+v"(q5.x), "+v"(q6.x));
+    bool pop = false;    // this subtree is done: take the next one from the stack (one site for both kinds of step)
     uint32_t units = 2u;
-    if (in_leaf) {
-        bvh_test_record(sc, q0, q1, q2, q3, s.leaf_cur, s);
-        if (second) bvh_test_record(sc, q4, q5, q6, q7, s.leaf_cur + 1u, s);
-        s.leaf_cur += second ? 2u : 1u;
-        pop = s.leaf_cur == s.leaf_end;
-        units = second ? 2u : 1u;
-    } else {
+    if (!in_leaf) {
         // q0..q5 = lox, loy, loz, hix, hiy, hiz of the four children; q6 = their references
         f32x2 tnA, tfA, tnB, tfB;
         box_entry2(f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, f32x2{q3.x, q3.y}, f32x2{q4.x, q4.y}, f32x2{q5.x, q5.y}, s.inv,
@@ -265,6 +264,17 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
                 if (p0) { stk.put(s.sp, e0); ++s.sp; }
             }
             trav_enter(s, j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3)));
+        }
+    } else {
+        bvh_test_record(sc, q0, q1, q2, q3, s.leaf_cur, s);
+        if (BVH_MAX_LEAF > 1) {
+            if (second) bvh_test_record(sc, q4, q5, q6, q7, s.leaf_cur + 1u, s);
+            s.leaf_cur += second ? 2u : 1u;
+            pop = s.leaf_cur == s.leaf_end;
+            units = second ? 2u : 1u;
+        } else {
+            pop = true;
+            units = 1u;
         }
     }
     if (pop) trav_pop(s, stk);
