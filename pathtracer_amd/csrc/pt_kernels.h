@@ -253,6 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
 #define PT_DYN_STEPS 8
 #endif
 constexpr uint32_t DYN_TILES = PT_DYN_TILES;   // wave-tiles (of 64 records) per chunk
+static_assert(DYN_TILES >= 1 && DYN_TILES <= 64 && (DYN_TILES & (DYN_TILES - 1)) == 0, "a chunk's tiles are described by the first lanes of a wave");
 constexpr int DYN_STEPS = PT_DYN_STEPS;        // traversal steps between refill checks
 
 #ifndef PT_TRACE_WAVES
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
     const unsigned long long lt = (1ull << lane_id()) - 1ull;
     const uint32_t n_chunks = (m.total + DYN_TILES - 1) / DYN_TILES;
     uint32_t *work = L.count + 1;  // chunk counter: a spare word of the level's first counter line, zeroed per pass
-    uint32_t first_tile = 0, end = 0, next = 0, rec = 0;
+    uint32_t end = 0, next = 0, rec = 0;
+    uint32_t tile_base = 0, tile_cnt = 0;   // lane t < DYN_TILES: first record and record count of tile t of the wave's chunk
     bool exhausted = false, active = false;
     Trav st;
     st.node = BVH_EMPTY;
@@ -283,32 +285,38 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
             if (lane_id() == 0) c = atomicAdd(work, 1u);
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
             if (c < n_chunks) {
-                first_tile = c * DYN_TILES;
-                end = (m.total - first_tile < DYN_TILES ? m.total - first_tile : DYN_TILES) * 64u;
+                const uint32_t first_tile = c * DYN_TILES;
+                const uint32_t tiles = m.total - first_tile < DYN_TILES ? m.total - first_tile : DYN_TILES;
+                end = tiles * 64u;
                 next = 0;
+                // where each tile of the chunk lies, found once per chunk (by the first lanes) instead of once per record
+                tile_cnt = 0;
+                if (lane_id() < tiles) {
+                    const uint32_t w = first_tile + lane_id();
+                    uint32_t lo = 0, hi = NSHARD - 1;  // first shard whose inclusive tile prefix exceeds w
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (s_incl[mid] > w) hi = mid; else lo = mid + 1;
+                    }
+                    const uint32_t before = lo ? s_incl[lo - 1] : 0u;
+                    const uint32_t off = (w - before) * 64u;
+                    tile_base = lo * L.shard_cap + off;
+                    tile_cnt = s_cnt[lo] > off ? s_cnt[lo] - off : 0u;   // (64 or more: a full tile)
+                }
             } else exhausted = true;
         }
         if (idle != 0 && next < end) {  // hand the next records of the chunk to the idle lanes
-            uint32_t k = next + (uint32_t)__popcll(idle & lt);
-            if (!active && k < end) {
-                uint32_t w = first_tile + (k >> 6);
-                uint32_t lo = 0, hi = NSHARD - 1;  // first shard whose inclusive tile prefix exceeds w
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (s_incl[mid] > w) hi = mid; else lo = mid + 1;
-                }
-                uint32_t before = lo ? s_incl[lo - 1] : 0u;
-                uint32_t off = (w - before) * 64u + (k & 63u);
-                if (off < s_cnt[lo]) {
-                    rec = lo * L.shard_cap + off;
-                    float4 a = L.rayA()[rec], b = L.rayB()[rec];
-                    bvh_begin(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), st);
-                    active = true;
+            const uint32_t k = next + (uint32_t)__popcll(idle & lt);
+            const uint32_t base = (uint32_t)__shfl((int)tile_base, (int)((k >> 6) & (DYN_TILES - 1))), cnt = (uint32_t)__shfl((int)tile_cnt, (int)((k >> 6) & (DYN_TILES - 1)));
+            if (!active && k < end && (k & 63u) < cnt) {
+                rec = base + (k & 63u);
+                float4 a = L.rayA()[rec], b = L.rayB()[rec];
+                bvh_begin(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), st);
+                active = true;
 #ifdef PT_TRAV_STATS
-                    if (ray_steps > max_steps) max_steps = ray_steps;
-                    ray_steps = 0;
+                if (ray_steps > max_steps) max_steps = ray_steps;
+                ray_steps = 0;
 #endif
-                }
             }
             next += (uint32_t)__popcll(idle);
         }
