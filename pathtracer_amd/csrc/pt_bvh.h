@@ -7,34 +7,38 @@
 //   * a candidate replaces the current best when (t, id) is lexicographically smaller, which is what
 //     "strictly closer wins, ties keep the earlier id" means and makes the result independent of visit order;
 //   * boxes are padded on the host (see BvhBuilder) by far more than the rounding of the hit point and of the
-//     slab test, a subtree is culled only when its entry distance is strictly beyond the best t, and NaN
-//     slab distances are ignored, so no primitive the linear scan would accept is ever skipped.
+//     slab test and are only ever rounded outwards, a subtree is culled only when its entry distance is strictly
+//     beyond the best t, and NaN slab distances are ignored, so no primitive the linear scan would accept is ever
+//     skipped.
 //
-// Node = 128 bytes (one cache line): the boxes of up to FOUR children, component-wise (lo.x of all four, lo.y of
-// all four, ...), so one fetch decides four subtrees and the slab tests run as 2-wide packed f32 operations.
-// Children: >= 0 inner node index, < 0 leaf (~c = first << 3 | count-1 into bvh_geom, ids ascending),
-// BVH_EMPTY = no child.  The tree is the binary SAH tree with every other level folded into its parent.
+// What bounds this loop is the number of load instructions a lane issues: measured on the 1M-rectangle field, the
+// texture-address unit of every CU is 80-90 % busy with one slot per lane and load instruction, whatever the width of
+// the load (two extra one-word loads per step cost 22 %).  A 16-byte load being the widest there is, the tree is laid
+// out for the fewest of them:
 //
-// Leaf primitives live in their own array in leaf order (bvh_geom, 64 bytes each: the plane's four vectors or the
-// sphere's one, primitive id in the last word), so a leaf test is ONE dependent fetch after the node.  The
-// traversal step below loads up to 128 bytes from "wherever this lane is" - an inner node or the next two
-// primitives of its leaf - and then either descends or tests: every lane of a wave makes progress on every memory
-// round trip, which is what bounds this loop (measured on the 2-wide version: the texture/L1 path ~40 % busy, waves
-// parked on memory 56 % of the time; halving the number of dependent fetches per ray is what the 4-wide node is for).
+// The tree lives in one array of 64-byte UNITS.  A unit is either a node (48 bytes used: three loads) or one leaf
+// primitive (the plane's four vectors or the sphere's one, primitive id in the last word: four loads).  The up to four
+// children of a node occupy consecutive units, so a node names them by the index of the first:
+//   word  0..2   origin of the node's grid (x, y, z; f32)
+//   word  3      byte 0..2: binary exponents ex, ey, ez of the grid's cell size (signed); byte 3: bit i set = child i is
+//                a leaf primitive
+//   word  4..9   the children's boxes on that grid, 8 bits a coordinate: words 4, 5 = x (child 0 and 1, child 2 and 3),
+//                6, 7 = y, 8, 9 = z; a child's 16 bits are lo | hi << 8.  A child that does not exist has lo = 255,
+//                hi = 0: no ray enters it
+//   word  10     unit index of child 0
+// A box coordinate is origin + q * 2^e; the slab distance (origin + q * 2^e - o) / d is evaluated as
+// q * (2^e / d) + (origin / d - o / d): one conversion and one fused multiply-add per plane after six operations per
+// node.  Lower corners are rounded down and upper ones up on the host, so a quantised box contains the padded box.
+// A reference to a unit: its index, with bit 31 set when the unit is a leaf primitive.  BVH_EMPTY (bit 31 alone: unit
+// 0 is the root and never a leaf) marks a finished traversal.
 #pragma once
 
 #include "pt_scene.h"
 
 namespace pt {
 
-struct BvhNode {
-    float4 lox, loy, loz, hix, hiy, hiz;   // .x = child 0 ... .w = child 3
-    int32_t c[4];
-    uint32_t pad[4];
-};
-static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
-
 constexpr int32_t BVH_EMPTY = (int32_t)0x80000000;
+constexpr uint32_t BVH_MAX_UNITS = 1u << 26;  // unit index << 6 is a 32-bit byte offset
 constexpr int BVH_BINARY_DEPTH = 38;   // depth cap of the binary tree the builder starts from
 constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 3 per level of the 4-wide tree, whose depth the builder
                                        // keeps at or below BVH_STACK / 3 (BvhBuilder::build)
@@ -43,32 +47,13 @@ constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 
 #endif
 constexpr int BVH_LDS_ENTRIES = PT_BVH_LDS_ENTRIES;    // of which this many live in LDS, the rest (rarely reached) in a global spill area
 constexpr int BVH_STACK_STRIDE = 256;  // threads per block of every kernel that traverses
-#ifndef PT_BVH_MAX_LEAF
-#define PT_BVH_MAX_LEAF 1
-#endif
-constexpr int BVH_MAX_LEAF = PT_BVH_MAX_LEAF;  // primitives per leaf (at most 8: three bits of the leaf reference); measured on the
-                                               // 1M-rectangle field: 1 -> 3750, 2 -> 3650, 3 -> 3560, 4 -> 3440, 8 -> 3140 Mrays/s
+constexpr int BVH_MAX_LEAF = 1;        // primitives per leaf; measured on the 1M-rectangle field with 128-byte nodes:
+                                       // 1 -> 3750, 2 -> 3650, 3 -> 3560, 4 -> 3440, 8 -> 3140 Mrays/s
+constexpr int BVH_MAX_EXPONENT = 62;   // primitives reaching beyond 2^61 stay outside the tree: with the reciprocal direction capped at 2^64 and
+                                       // cells of at most 2^55, the slab products of everything inside stay finite
 constexpr uint32_t BVH_TRAV_BLOCKS = 2048;  // most blocks a traversing kernel is launched with (sizes the spill area)
 
 #if defined(__HIPCC__)
-// Slab test of two children at once (called twice per node).  Distances are lo * inv + (-o * inv) in one fused
-// operation per plane pair (v_pk_fma_f32); against (lo - o) * inv that moves a slab by at most ~|o| * 2^-23, far
-// inside the builder's padding.  inv is finite (slab_reciprocal); a NaN distance (0 * inf cannot occur any more, but a
-// NaN ray can) drops out of fminf/fmaxf; tfar is widened by 4 ulp for the rounding of the products.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 min2(f32x2 x, f32x2 y) { return f32x2{fminf(x.x, y.x), fminf(x.y, y.y)}; }
-__device__ __forceinline__ f32x2 max2(f32x2 x, f32x2 y) { return f32x2{fmaxf(x.x, y.x), fmaxf(x.y, y.y)}; }
-__device__ __forceinline__ void box_entry2(f32x2 lox, f32x2 loy, f32x2 loz, f32x2 hix, f32x2 hiy, f32x2 hiz, V3 inv, V3 noi, f32x2 &tn,
-                                           f32x2 &tf) {
-    f32x2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    f32x2 nx = {noi.x, noi.x}, ny = {noi.y, noi.y}, nz = {noi.z, noi.z};
-    f32x2 t0x = __builtin_elementwise_fma(lox, ix, nx), t1x = __builtin_elementwise_fma(hix, ix, nx);
-    f32x2 t0y = __builtin_elementwise_fma(loy, iy, ny), t1y = __builtin_elementwise_fma(hiy, iy, ny);
-    f32x2 t0z = __builtin_elementwise_fma(loz, iz, nz), t1z = __builtin_elementwise_fma(hiz, iz, nz);
-    tn = max2(max2(min2(t0x, t1x), min2(t0y, t1y)), max2(min2(t0z, t1z), f32x2{0.0f, 0.0f}));
-    tf = min2(min2(max2(t0x, t1x), max2(t0y, t1y)), max2(t0z, t1z)) * 1.0000005f;
-}
-
 // 1/d for the slab test, with its magnitude capped at 2^64.  An infinite reciprocal (a direction component that is
 // zero, as in the centre column of an un-jittered image, or denormal) would make lo * inv - o * inv the difference of
 // two infinities whenever lo and o have the same sign; the NaN would drop out of fminf/fmaxf and leave the slab's
@@ -84,7 +69,7 @@ __device__ __forceinline__ float slab_reciprocal(float d) {
 
 // A candidate replaces the current nearest when (t, id) is lexicographically smaller.
 // While nothing is hit, best == MISS (the largest id) and best_t == +inf, so the first hit always wins.
-// `slot`: where the primitive's shading row is (its position in bvh_geom, or behind them for the `always` list).
+// `slot`: where the primitive's shading row is (the index of its unit, or behind all units for the `always` list).
 __device__ __forceinline__ void bvh_accept(bool hit, float t, uint32_t id, int out, uint32_t slot, uint32_t &best, float &best_t, int &best_out,
                                            uint32_t &best_slot) {
     if (hit && (t < best_t || (t == best_t && id < best))) { best = id; best_t = t; best_out = out; best_slot = slot; }
@@ -104,7 +89,7 @@ __device__ __forceinline__ void bvh_test_prims(const DevScene &sc, const uint32_
             V3 pos;
             hit = plane_test(sc.pln[4 * p], sc.pln[4 * p + 1], sc.pln[4 * p + 2], sc.pln[4 * p + 3], o, d, t, pos);
         }
-        bvh_accept(hit, t, id, out, sc.n_leaf_prims + k, best, best_t, best_out, best_slot);
+        bvh_accept(hit, t, id, out, sc.n_bvh_units + k, best, best_t, best_out, best_slot);
     }
 }
 
@@ -147,27 +132,20 @@ __device__ __forceinline__ TravStack trav_stack(const DevScene &sc) {
     return s;
 }
 
-// Traversal state of one ray.  node >= 0: at an inner node; node < 0 (not BVH_EMPTY): inside a leaf, primitives
-// leaf_cur .. leaf_end-1 of bvh_geom still to test; node == BVH_EMPTY: finished, (best, best_t) is the answer.
+// Traversal state of one ray.  node >= 0: at an inner node (its unit index); node < 0 (not BVH_EMPTY): at a leaf
+// primitive (unit index | bit 31); node == BVH_EMPTY: finished, (best, best_t) is the answer.
 struct Trav {
     V3 o, d, inv, noi;   // noi = -o * inv
+    uint32_t selx, sely, selz;  // byte selectors that bring a box word into (near, far, near, far) order for this ray's direction
     uint32_t best;
     float best_t;
     int best_out;        // Transition of the best hit (1: a sphere left from inside)
     uint32_t best_slot;  // its row in sc.shade_rows
     int32_t node;
     int sp;
-    uint32_t leaf_cur, leaf_end;
 };
 
-__device__ __forceinline__ void trav_enter(Trav &s, int32_t ref) {
-    s.node = ref;
-    if (ref < 0) {
-        uint32_t payload = (uint32_t)~ref;
-        s.leaf_cur = payload >> 3;
-        if (BVH_MAX_LEAF > 1) s.leaf_end = s.leaf_cur + (payload & 7u) + 1u;
-    }
-}
+__device__ __forceinline__ void trav_enter(Trav &s, int32_t ref) { s.node = ref; }
 
 // Next subtree from the stack; entries whose entry distance is strictly beyond the current best are dropped
 // without touching memory (the same rule that decides whether a child is visited at all).
@@ -189,12 +167,16 @@ __device__ __forceinline__ void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &
     bvh_test_prims(sc, sc.bvh_always, sc.n_always, o, d, s.best, s.best_t, s.best_out, s.best_slot);
     s.inv = v3(slab_reciprocal(d.x), slab_reciprocal(d.y), slab_reciprocal(d.z));
     s.noi = v3(-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z));
+    // a box word holds (lo, hi) of two children; a ray that runs towards smaller coordinates enters through hi
+    const uint32_t KEEP = 0x03020100u, SWAP = 0x02030001u;
+    s.selx = s.inv.x < 0.0f ? SWAP : KEEP;
+    s.sely = s.inv.y < 0.0f ? SWAP : KEEP;
+    s.selz = s.inv.z < 0.0f ? SWAP : KEEP;
     s.node = 0;
     s.sp = 0;
-    s.leaf_cur = s.leaf_end = 0;
 }
 
-// One primitive record of bvh_geom against the ray.
+// One leaf primitive (the four vectors of its unit) against the ray.
 __device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, float4 b, float4 c, float4 e, uint32_t slot, Trav &s) {
     uint32_t id = __float_as_uint(e.w);
     float t;
@@ -205,38 +187,54 @@ __device__ __forceinline__ void bvh_test_record(const DevScene &sc, float4 a, fl
     bvh_accept(hit, t, id, out, slot, s.best, s.best_t, s.best_out, s.best_slot);
 }
 
-// One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of up to 128 bytes, then either the four
-// box tests of an inner node (nearest hit child next, the other hit children pushed with their entry distances) or
-// up to two primitives of the current leaf.  Returns the number of 64-byte units it fetched.
+// Entry and exit distance of two children along one axis: w = their (lo, hi) bytes, A = cell size / d, B = (origin - o) / d.
+__device__ __forceinline__ void slab_pair(uint32_t w, uint32_t sel, float A, float B, float &n0, float &f0, float &n1, float &f1) {
+    const uint32_t v = __builtin_amdgcn_perm(w, w, sel);   // (the byte extractions below are one v_cvt_f32_ubyteN each)
+    n0 = __builtin_fmaf((float)((v >> 0) & 0xffu), A, B);
+    f0 = __builtin_fmaf((float)((v >> 8) & 0xffu), A, B);
+    n1 = __builtin_fmaf((float)((v >> 16) & 0xffu), A, B);
+    f1 = __builtin_fmaf((float)((v >> 24) & 0xffu), A, B);
+}
+
+// One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of the unit the lane stands on, then either the
+// four box tests of a node (nearest hit child next, the other hit children pushed with their entry distances) or the
+// test of a leaf primitive.  Returns the number of units it fetched (1).
 __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk) {
     const bool in_leaf = s.node < 0;
-    const float4 *p = in_leaf ? sc.bvh_geom + 4 * (size_t)s.leaf_cur : reinterpret_cast<const float4 *>(sc.bvh_nodes + s.node);
-    // the second half of the line: an inner node's upper corners and references, or a leaf's second primitive
-    const bool second = !in_leaf || (BVH_MAX_LEAF > 1 && s.leaf_cur + 1u < s.leaf_end);
-    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    float4 q4, q5, q6, q7;
-    if (second) { q4 = p[4]; q5 = p[5]; q6 = p[6]; if (BVH_MAX_LEAF > 1 && in_leaf) q7 = p[7]; }
-    // All of the line is requested here, in one round trip.  Without this (empty) statement that names the second half,
-    // the compiler moves those loads down into the inner-node arm, behind the primitive test of the lanes that are in a
-    // leaf: a second round trip per step for every lane of the wave.
-    asm volatile("" : "+v"(q4.x), "+v"(q5.x), "+v"(q6.x));
+    // (the shift drops bit 31; a 32-bit offset from a base all lanes share keeps the base in scalar registers)
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.bvh_nodes) + (size_t)((uint32_t)s.node << 6));
+    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    float4 q3;
+    if (in_leaf) q3 = p[3];
+    // The whole unit is requested here, in one round trip.  Without this (empty) statement that names the last vector,
+    // the compiler moves its load down into the leaf arm, behind the box tests: a second round trip per step.
+    asm volatile("" : "+v"(q3.x));
     bool pop = false;    // this subtree is done: take the next one from the stack (one site for both kinds of step)
-    uint32_t units = 2u;
     if (!in_leaf) {
-        // q0..q5 = lox, loy, loz, hix, hiy, hiz of the four children; q6 = their references
-        f32x2 tnA, tfA, tnB, tfB;
-        box_entry2(f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, f32x2{q3.x, q3.y}, f32x2{q4.x, q4.y}, f32x2{q5.x, q5.y}, s.inv,
-                   s.noi, tnA, tfA);
-        box_entry2(f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, f32x2{q3.z, q3.w}, f32x2{q4.z, q4.w}, f32x2{q5.z, q5.w}, s.inv,
-                   s.noi, tnB, tfB);
-        const int32_t c0 = (int32_t)__float_as_uint(q6.x), c1 = (int32_t)__float_as_uint(q6.y);
-        const int32_t c2 = (int32_t)__float_as_uint(q6.z), c3 = (int32_t)__float_as_uint(q6.w);
+        const uint32_t meta = __float_as_uint(q0.w);
+        const float Ax = __builtin_ldexpf(s.inv.x, (int)(int8_t)(meta & 0xffu)), Bx = __builtin_fmaf(q0.x, s.inv.x, s.noi.x);
+        const float Ay = __builtin_ldexpf(s.inv.y, (int)(int8_t)((meta >> 8) & 0xffu)), By = __builtin_fmaf(q0.y, s.inv.y, s.noi.y);
+        const float Az = __builtin_ldexpf(s.inv.z, (int)(int8_t)((meta >> 16) & 0xffu)), Bz = __builtin_fmaf(q0.z, s.inv.z, s.noi.z);
+        float nx0, fx0, nx1, fx1, nx2, fx2, nx3, fx3, ny0, fy0, ny1, fy1, ny2, fy2, ny3, fy3, nz0, fz0, nz1, fz1, nz2, fz2, nz3, fz3;
+        slab_pair(__float_as_uint(q1.x), s.selx, Ax, Bx, nx0, fx0, nx1, fx1);
+        slab_pair(__float_as_uint(q1.y), s.selx, Ax, Bx, nx2, fx2, nx3, fx3);
+        slab_pair(__float_as_uint(q1.z), s.sely, Ay, By, ny0, fy0, ny1, fy1);
+        slab_pair(__float_as_uint(q1.w), s.sely, Ay, By, ny2, fy2, ny3, fy3);
+        slab_pair(__float_as_uint(q2.x), s.selz, Az, Bz, nz0, fz0, nz1, fz1);
+        slab_pair(__float_as_uint(q2.y), s.selz, Az, Bz, nz2, fz2, nz3, fz3);
+        // (NaN distances - a NaN ray - drop out of fminf/fmaxf; the far distance is widened for the rounding of the products)
+        const float WIDEN = 1.0000005f;
+        const float tn0 = fmaxf(fmaxf(nx0, ny0), fmaxf(nz0, 0.0f)), tf0 = fminf(fminf(fx0, fy0), fz0) * WIDEN;
+        const float tn1 = fmaxf(fmaxf(nx1, ny1), fmaxf(nz1, 0.0f)), tf1 = fminf(fminf(fx1, fy1), fz1) * WIDEN;
+        const float tn2 = fmaxf(fmaxf(nx2, ny2), fmaxf(nz2, 0.0f)), tf2 = fminf(fminf(fx2, fy2), fz2) * WIDEN;
+        const float tn3 = fmaxf(fmaxf(nx3, ny3), fmaxf(nz3, 0.0f)), tf3 = fminf(fminf(fx3, fy3), fz3) * WIDEN;
         const float INF = __builtin_inff();
-        // key = entry distance of a child the ray must visit, +inf otherwise
-        float k0 = (c0 != BVH_EMPTY && tnA.x <= tfA.x && tnA.x <= s.best_t) ? tnA.x : INF;
-        float k1 = (c1 != BVH_EMPTY && tnA.y <= tfA.y && tnA.y <= s.best_t) ? tnA.y : INF;
-        float k2 = (c2 != BVH_EMPTY && tnB.x <= tfB.x && tnB.x <= s.best_t) ? tnB.x : INF;
-        float k3 = (c3 != BVH_EMPTY && tnB.y <= tfB.y && tnB.y <= s.best_t) ? tnB.y : INF;
+        // key = entry distance of a child the ray must visit, +inf otherwise (a child that does not exist is never entered:
+        // its box is inside out)
+        float k0 = (tn0 <= tf0 && tn0 <= s.best_t) ? tn0 : INF;
+        float k1 = (tn1 <= tf1 && tn1 <= s.best_t) ? tn1 : INF;
+        float k2 = (tn2 <= tf2 && tn2 <= s.best_t) ? tn2 : INF;
+        float k3 = (tn3 <= tf3 && tn3 <= s.best_t) ? tn3 : INF;
         // (a child entered at distance +inf cannot hold a finite hit, so treating it as missed loses nothing)
         int j = 0;
         float kj = k0;
@@ -245,6 +243,10 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
         if (k3 < kj) { kj = k3; j = 3; }
         pop = kj == INF;
         if (!pop) {
+            const uint32_t base = __float_as_uint(q2.z);
+            const uint32_t leaf = meta >> 24;   // bit i: child i is a leaf primitive
+            const int32_t c0 = (int32_t)((base + 0u) | ((leaf & 1u) << 31)), c1 = (int32_t)((base + 1u) | ((leaf & 2u) << 30));
+            const int32_t c2 = (int32_t)((base + 2u) | ((leaf & 4u) << 29)), c3 = (int32_t)((base + 3u) | ((leaf & 8u) << 28));
             // the others in fixed order; entries are culled by distance again when they are popped
             const bool p3 = j != 3 && k3 < INF, p2 = j != 2 && k2 < INF, p1 = j != 1 && k1 < INF, p0 = j != 0 && k0 < INF;
             const unsigned long long e3 = stack_entry(c3, k3), e2 = stack_entry(c2, k2), e1 = stack_entry(c1, k1), e0 = stack_entry(c0, k0);
@@ -266,19 +268,11 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
             trav_enter(s, j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3)));
         }
     } else {
-        bvh_test_record(sc, q0, q1, q2, q3, s.leaf_cur, s);
-        if (BVH_MAX_LEAF > 1) {
-            if (second) bvh_test_record(sc, q4, q5, q6, q7, s.leaf_cur + 1u, s);
-            s.leaf_cur += second ? 2u : 1u;
-            pop = s.leaf_cur == s.leaf_end;
-            units = second ? 2u : 1u;
-        } else {
-            pop = true;
-            units = 1u;
-        }
+        bvh_test_record(sc, q0, q1, q2, q3, (uint32_t)s.node & 0x7fffffffu, s);
+        pop = true;
     }
     if (pop) trav_pop(s, stk);
-    return units;
+    return 1u;
 }
 
 // Is the terminal light sample at distance `light_distance` along (o, d) lit?  The reference asks for the NEAREST hit and

@@ -25,9 +25,10 @@
 namespace pt {
 
 struct BvhBuilder {
-    std::vector<BvhNode> nodes;
-    std::vector<uint32_t> prims;   // leaf primitive ids, in leaf order
-    std::vector<float4> geom;      // the same primitives' geometry, 4 vectors each, id in the last word (device bvh_geom)
+    std::vector<float4> units;     // the tree as the device reads it: 4 vectors per 64-byte unit (pt_bvh.h)
+    std::vector<uint32_t> unit_prim;  // per unit: the primitive id of a leaf unit, MISS_ID for a node
+    uint64_t n_nodes = 0, n_leaf_prims = 0;
+    static constexpr uint32_t MISS_ID = 0xffffffffu;
     std::vector<uint32_t> always;  // primitives tested for every ray
     int max_depth_seen = 0;        // depth of the binary tree (root = 0)
     int depth4 = 0;                // levels of inner nodes of the 4-wide tree: a traversal holds at most 3 * depth4 stack entries
@@ -56,6 +57,11 @@ struct BvhBuilder {
     const std::vector<float4> *src_sph = nullptr, *src_pln = nullptr;
 
     static bool finite3(double a, double b, double c) { return std::isfinite(a) && std::isfinite(b) && std::isfinite(c); }
+    // Beyond 2^BVH_MAX_EXPONENT the products of the device's slab test could overflow: such a primitive is tested for every ray.
+    static bool too_far(double x, double y, double z, double reach) {
+        const double lim = std::ldexp(1.0, BVH_MAX_EXPONENT - 1);
+        return std::fabs(x) + reach > lim || std::fabs(y) + reach > lim || std::fabs(z) + reach > lim;
+    }
 
     // The padded box of everything the tree holds: a ray that misses it misses every primitive - provided nothing is
     // on the `always` list.  Call after boxes().  False: no usable bound (unboundable primitives, or nothing at all).
@@ -69,13 +75,17 @@ struct BvhBuilder {
 
     void build(const std::vector<float4> &sph, const std::vector<float4> &pln, V3 cam_pos, V3 cam_plane_origin) {
         boxes(sph, pln, cam_pos, cam_plane_origin);
-        nodes.clear();
-        prims.clear();
+        units.clear();
+        unit_prim.clear();
+        n_nodes = n_leaf_prims = 0;
         bn.clear();
-        if (idx.empty()) {  // nothing boundable: a root with two empty children
-            BvhNode root{};
-            root.c[0] = root.c[1] = root.c[2] = root.c[3] = BVH_EMPTY;
-            nodes.push_back(root);
+        if (idx.empty()) {  // nothing boundable: a root without children
+            const int32_t none[1] = {0};
+            units.assign(4, make_float4(0.f, 0.f, 0.f, 0.f));
+            unit_prim.assign(1, MISS_ID);
+            write_node(0, none, 0, 0);
+            n_nodes = 1;
+            depth4 = 1;
             return;
         }
         bn.reserve(idx.size());
@@ -99,7 +109,6 @@ struct BvhBuilder {
         const uint32_t n_sph = (uint32_t)sph.size(), n_pl = (uint32_t)(pln.size() / 4);
         const uint32_t n = n_sph + n_pl;
         src_sph = &sph; src_pln = &pln;
-        geom.clear();
         always.clear();
         pbox.resize(n);
         pcent.resize(3 * (size_t)n);
@@ -113,7 +122,7 @@ struct BvhBuilder {
             const float4 s = sph[i];
             Box &b = pbox[i];
             double r = std::fabs((double)s.w);
-            if (!finite3(s.x, s.y, s.z) || !std::isfinite(r)) { always.push_back(i); continue; }
+            if (!finite3(s.x, s.y, s.z) || !std::isfinite(r) || too_far(s.x, s.y, s.z, r)) { always.push_back(i); continue; }
             b.lo[0] = s.x - r; b.lo[1] = s.y - r; b.lo[2] = s.z - r;
             b.hi[0] = s.x + r; b.hi[1] = s.y + r; b.hi[2] = s.z + r;
             idx.push_back(i);
@@ -128,6 +137,7 @@ struct BvhBuilder {
             double c = un[0] * vn[0] + un[1] * vn[1] + un[2] * vn[2];
             bool ok = finite3(s[0], s[1], s[2]) && finite3(un[0], un[1], un[2]) && finite3(vn[0], vn[1], vn[2]) && std::isfinite(ul) &&
                       std::isfinite(vl) && std::fabs(c) < 0.999;
+            ok = ok && !too_far(s[0], s[1], s[2], std::fabs(ul) + std::fabs(vl));
             if (!ok) { always.push_back(id); continue; }
             Box &b = pbox[id];
             b.reset();
@@ -165,7 +175,7 @@ struct BvhBuilder {
         bn.emplace_back();
         bn[me].box = range_box(first, count);
         bn[me].first = first; bn[me].count = count;
-        if (count <= (uint32_t)BVH_MAX_LEAF) return me;
+        if (count <= (uint32_t)BVH_MAX_LEAF) return me;   // (one primitive: median splits by index always get there)
         // Children sit one level deeper; a leaf holds BVH_MAX_LEAF.  Force a median split when SAH imbalance
         // could otherwise exceed the traversal stack.
         const int remaining = BVH_BINARY_DEPTH - depth;
@@ -232,29 +242,61 @@ struct BvhBuilder {
     static float down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
     static float up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
 
-    int32_t child_ref(int32_t b, std::vector<int32_t> &inner_index) {
-        const BuildNode &n = bn[b];
-        if (n.left < 0) {  // leaf
-            uint32_t first = (uint32_t)prims.size();
-            std::vector<uint32_t> ids(idx.begin() + n.first, idx.begin() + n.first + n.count);
-            std::sort(ids.begin(), ids.end());
-            prims.insert(prims.end(), ids.begin(), ids.end());
-            const uint32_t n_sph = (uint32_t)src_sph->size();
-            for (uint32_t id : ids) {
-                float4 q[4] = {};
-                if (id < n_sph) q[0] = (*src_sph)[id];
-                else for (int k = 0; k < 4; ++k) q[k] = (*src_pln)[4 * (size_t)(id - n_sph) + k];
-                std::memcpy(&q[3].w, &id, 4);
-                geom.insert(geom.end(), q, q + 4);
-            }
-            return ~(int32_t)((first << 3) | (n.count - 1));
-        }
-        return inner_index[b];
+    // The unit of a leaf primitive: the plane's four vectors or the sphere's one, the primitive id in the last word.
+    void write_leaf(uint32_t unit, const BuildNode &n) {
+        const uint32_t id = idx[n.first];
+        const uint32_t n_sph = (uint32_t)src_sph->size();
+        float4 q[4] = {};
+        if (id < n_sph) q[0] = (*src_sph)[id];
+        else for (int k = 0; k < 4; ++k) q[k] = (*src_pln)[4 * (size_t)(id - n_sph) + k];
+        std::memcpy(&q[3].w, &id, 4);
+        std::copy(q, q + 4, units.begin() + 4 * (size_t)unit);
+        unit_prim[unit] = id;
+        ++n_leaf_prims;
     }
 
-    void set_box(BvhNode &N, int which, const Box &b) {
-        float *lo[3] = {&N.lox.x, &N.loy.x, &N.loz.x}, *hi[3] = {&N.hix.x, &N.hiy.x, &N.hiz.x};
-        for (int d = 0; d < 3; ++d) { lo[d][which] = down(b.lo[d] - pad); hi[d][which] = up(b.hi[d] + pad); }
+    // The unit of a node whose n children (binary nodes ch[0..n-1]) occupy the units first_child .. first_child + n - 1:
+    // the children's padded boxes on a grid of 255 cells per axis that starts at the lowest padded corner; lower corners
+    // rounded down, upper ones up, so every quantised box contains the padded one (layout: pt_bvh.h).
+    void write_node(uint32_t unit, const int32_t *ch, int n, uint32_t first_child) {
+        float lo[4][3], hi[4][3];
+        for (int j = 0; j < n; ++j)
+            for (int d = 0; d < 3; ++d) { lo[j][d] = down(bn[ch[j]].box.lo[d] - pad); hi[j][d] = up(bn[ch[j]].box.hi[d] + pad); }
+        float org[3] = {0.f, 0.f, 0.f};
+        int ex[3] = {0, 0, 0};
+        uint8_t qlo[4][3], qhi[4][3];
+        for (int j = 0; j < 4; ++j) for (int d = 0; d < 3; ++d) { qlo[j][d] = 255; qhi[j][d] = 0; }   // no such child: inside out
+        for (int d = 0; d < 3 && n > 0; ++d) {
+            double lo_min = lo[0][d], hi_max = hi[0][d];
+            for (int j = 1; j < n; ++j) { lo_min = std::min<double>(lo_min, lo[j][d]); hi_max = std::max<double>(hi_max, hi[j][d]); }
+            org[d] = (float)lo_min;
+            const double ext = hi_max - lo_min;
+            int e = -100;
+            if (ext > 0.0) { e = std::max(-100, std::ilogb(ext / 255.0)); while (255.0 * std::ldexp(1.0, e) < ext) ++e; }
+            ex[d] = e;   // (at most BVH_MAX_EXPONENT - 7: boxes() keeps the extent below 2^BVH_MAX_EXPONENT)
+            const double cell = std::ldexp(1.0, e);
+            for (int j = 0; j < n; ++j) {
+                double a = std::floor((lo[j][d] - lo_min) / cell), b = std::ceil((hi[j][d] - lo_min) / cell);
+                while (lo_min + a * cell > lo[j][d]) a -= 1.0;
+                while (lo_min + b * cell < hi[j][d]) b += 1.0;
+                qlo[j][d] = (uint8_t)std::min(255.0, std::max(0.0, a));
+                qhi[j][d] = (uint8_t)std::min(255.0, std::max(0.0, b));
+            }
+        }
+        uint32_t leaf_bits = 0;
+        for (int j = 0; j < n; ++j) if (bn[ch[j]].left < 0) leaf_bits |= 1u << j;
+        uint32_t w[16] = {};
+        std::memcpy(&w[0], org, 12);
+        w[3] = (uint32_t)(uint8_t)(int8_t)ex[0] | (uint32_t)(uint8_t)(int8_t)ex[1] << 8 | (uint32_t)(uint8_t)(int8_t)ex[2] << 16 | leaf_bits << 24;
+        for (int d = 0; d < 3; ++d)
+            for (int half = 0; half < 2; ++half) {
+                const int j0 = 2 * half, j1 = 2 * half + 1;
+                w[4 + 2 * d + half] = (uint32_t)qlo[j0][d] | (uint32_t)qhi[j0][d] << 8 | (uint32_t)qlo[j1][d] << 16 | (uint32_t)qhi[j1][d] << 24;
+            }
+        w[10] = first_child;
+        std::memcpy(&units[4 * (size_t)unit], w, 64);
+        unit_prim[unit] = MISS_ID;
+        ++n_nodes;
     }
 
     // Children of the 4-wide node rooted at binary node b: b's two children, then the inner one with the largest
@@ -287,54 +329,42 @@ struct BvhBuilder {
     }
 
     void flatten() {
-        // 4-wide nodes get device indices in depth-first preorder: a node's first inner child is the next 128
-        // bytes, a subtree is one contiguous run, and - leaves being emitted in the same order - so is its
-        // geometry; rays that are close in space then share cache lines on the way down.
-        std::vector<int32_t> inner_index(bn.size(), -1), order;
-        nodes.clear();
-        prims.clear();
-        geom.clear();
+        // Unit 0 is the root.  A node's children get a run of consecutive units when the node is written; nodes are
+        // written depth first, so a subtree's units stay close together and rays that are close in space share cache
+        // lines on the way down.
+        units.assign(4, make_float4(0.f, 0.f, 0.f, 0.f));
+        unit_prim.assign(1, MISS_ID);
+        n_nodes = n_leaf_prims = 0;
         depth4 = 1;
+        auto grow = [&](int n) {
+            const uint32_t first = (uint32_t)unit_prim.size();
+            units.resize(units.size() + 4 * (size_t)n, make_float4(0.f, 0.f, 0.f, 0.f));
+            unit_prim.resize(unit_prim.size() + (size_t)n, MISS_ID);
+            return first;
+        };
         if (bn[0].left < 0) {  // a single leaf: wrap it in a root
-            BvhNode root{};
-            std::vector<int32_t> none;
-            set_box(root, 0, bn[0].box);
-            root.c[0] = child_ref(0, none);
-            root.c[1] = root.c[2] = root.c[3] = BVH_EMPTY;
-            nodes.push_back(root);
-            pad_geom();
+            const int32_t only[1] = {0};
+            const uint32_t first = grow(1);
+            write_node(0, only, 1, first);
+            write_leaf(first, bn[0]);
             return;
         }
-        std::vector<std::pair<int32_t, int>> todo{{0, 1}};  // (binary node, its level in the 4-wide tree)
+        struct Todo { int32_t b; uint32_t unit; int level; };   // (binary node, where its 4-wide node goes, its level in the 4-wide tree)
+        std::vector<Todo> todo{{0, 0u, 1}};
         while (!todo.empty()) {
-            const int32_t b = todo.back().first;
-            const int level = todo.back().second;
+            const Todo t = todo.back();
             todo.pop_back();
-            depth4 = std::max(depth4, level);
-            inner_index[b] = (int32_t)order.size();
-            order.push_back(b);
+            depth4 = std::max(depth4, t.level);
             int32_t ch[4];
-            int n = fold(b, ch);
-            for (int k = n - 1; k >= 0; --k)
-                if (bn[ch[k]].left >= 0) todo.push_back({ch[k], level + 1});
-        }
-        nodes.resize(order.size());
-        for (size_t k = 0; k < order.size(); ++k) {
-            int32_t ch[4];
-            int n = fold(order[k], ch);
-            BvhNode N{};
-            for (int j = 0; j < 4; ++j) {
-                if (j < n) { set_box(N, j, bn[ch[j]].box); N.c[j] = child_ref(ch[j], inner_index); }
-                else N.c[j] = BVH_EMPTY;
+            const int n = fold(t.b, ch);
+            const uint32_t first = grow(n);
+            write_node(t.unit, ch, n, first);
+            for (int k = n - 1; k >= 0; --k) {
+                if (bn[ch[k]].left >= 0) todo.push_back({ch[k], first + (uint32_t)k, t.level + 1});
+                else write_leaf(first + (uint32_t)k, bn[ch[k]]);
             }
-            nodes[k] = N;
         }
-        pad_geom();
     }
-
-    // The traversal fetches a leaf's primitives two records at a time but only when two are left, so no read goes
-    // past the array; one spare record keeps that true even if that rule is ever relaxed.
-    void pad_geom() { geom.insert(geom.end(), 4, make_float4(0.f, 0.f, 0.f, 0.f)); }
 };
 
 }  // namespace pt

@@ -22,8 +22,6 @@ enum : uint32_t { MAT_NONE = 0, MAT_EMISSIVE = 1, MAT_MIRROR = 2, MAT_TRANSLUCEN
 enum : int { TONE_CLAMP = 0, TONE_REINHARD = 1, TONE_EXPOSURE = 2 };
 enum : int { SKY_CONSTANT = 0, SKY_HDRI = 1 };
 
-struct BvhNode;  // pt_bvh.h
-
 // Device view of a Scene (reference src/scene.rs:151-160) after host-side flattening.  Primitive ids run
 // over spheres, emissive spheres, planes, emissive planes in that order (src/scene.rs:266,280).
 struct DevScene {
@@ -36,15 +34,15 @@ struct DevScene {
     const float4 *mat;       // [(n_sph + n_pl) * 4]  (kind, color.xyz) (roughness, metalness, ior, 0) (f0.xyz, 0) (PI*lambert.xyz, 0)
     const float4 *lights;    // [n_es] radiance of emissive spheres, then [n_ep * 4] emissive planes:
                              //   (origin.xyz, n.x) (n.yz, u.xy) (u.z, v.xyz) (radiance.xyz, 0)
-    const BvhNode *bvh_nodes;   // null: linear scan
-    const float4 *bvh_geom;     // [leaf prims * 4] primitives in leaf order: the plane's 4 vectors (or the sphere's one), id in the last word
+    const float4 *bvh_nodes;    // null: linear scan.  [units * 4] the tree: 64-byte units, each a node or a leaf primitive (pt_bvh.h)
     uint2 *bvh_spill;           // traversal stack entries beyond the LDS part (see pt_bvh.h)
     const uint32_t *bvh_always; // primitives that cannot be bounded: tested for every ray
     uint32_t n_always;
-    const float4 *shade_rows;   // [(leaf prims + n_always) * 4] what shading needs of a primitive, one 64-byte line each, in the order
-                                //   of bvh_geom (then the `always` list): (kind, color.xyz) (roughness, metalness, ior, bits(primitive id))
-                                //   (f0.xyz, 0) (plane normal or sphere centre .xyz, 0); the BVH trace kernel reports hits by this slot
-    uint32_t n_leaf_prims;      // slots of bvh_geom (the `always` primitives follow)
+    const float4 *shade_rows;   // [(units + n_always) * 4] what shading needs of a primitive, one 64-byte line each: row u belongs to
+                                //   the leaf primitive in unit u of the tree (rows of node units are unused), the `always` list follows:
+                                //   (kind, color.xyz) (roughness, metalness, ior, bits(primitive id)) (f0.xyz, 0) (plane normal or sphere
+                                //   centre .xyz, 0); the BVH trace kernel reports hits by this row
+    uint32_t n_bvh_units;       // units of the tree (the rows of the `always` primitives follow)
     // camera (reference src/tracer.rs:104-111: per-pixel step vectors of CameraSampler)
     V3 cam_origin, cam_su, cam_sv, cam_pos;
     int tone; float exposure; float iso_factor;

@@ -62,8 +62,7 @@ struct PtHandle {
     // device scene buffers
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
     float *d_sky = nullptr, *d_gamma = nullptr;
-    BvhNode *d_bvh_nodes = nullptr;
-    float4 *d_bvh_geom = nullptr, *d_shade_rows = nullptr;
+    float4 *d_bvh_nodes = nullptr, *d_shade_rows = nullptr;
     uint32_t *d_bvh_always = nullptr;
     uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
     uint64_t bvh_depth = 0, bvh_binary_depth = 0, bvh_forced_median_splits = 0, bvh_level_fold = 0;
@@ -183,7 +182,7 @@ void free_levels(PtHandle *h) {
 
 void free_scene(PtHandle *h) {
     dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
-    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_geom); dev_free(h->d_bvh_always); dev_free(h->d_shade_rows);
+    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_always); dev_free(h->d_shade_rows);
     dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
     if (h->h_pixels8) { (void)hipHostFree(h->h_pixels8); h->h_pixels8 = nullptr; }
     free_levels(h);
@@ -795,22 +794,24 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     if (want_bvh && n_sph + n_pl > 0) {
         BvhBuilder builder;
         builder.build(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
-        if ((rc = dev_alloc(h, &h->d_bvh_nodes, builder.nodes.size()))) return rc;
-        if ((rc = dev_alloc(h, &h->d_bvh_geom, std::max<size_t>(4, builder.geom.size())))) return rc;
-        HIPCHK(h, hipMemcpy(h->d_bvh_nodes, builder.nodes.data(), builder.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
-        if (!builder.geom.empty())
-            HIPCHK(h, hipMemcpy(h->d_bvh_geom, builder.geom.data(), builder.geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+        if (builder.unit_prim.size() > BVH_MAX_UNITS) {
+            return fail(h, PT_ERR_INVALID_ARGUMENT, "scene too large for the acceleration structure (more than 2^26 nodes and primitives)");
+        }
+        if ((rc = dev_alloc(h, &h->d_bvh_nodes, builder.units.size()))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_bvh_nodes, builder.units.data(), builder.units.size() * sizeof(float4), hipMemcpyHostToDevice));
         if ((rc = dev_alloc(h, &h->d_bvh_always, std::max<size_t>(1, builder.always.size())))) return rc;
         if (!builder.always.empty())
             HIPCHK(h, hipMemcpy(h->d_bvh_always, builder.always.data(), builder.always.size() * 4, hipMemcpyHostToDevice));
-        sc.bvh_nodes = h->d_bvh_nodes; sc.bvh_geom = h->d_bvh_geom;  // (the spill area belongs to the pipes)
+        sc.bvh_nodes = h->d_bvh_nodes;  // (the spill area belongs to the pipes)
         sc.bvh_always = h->d_bvh_always; sc.n_always = (uint32_t)builder.always.size();
-        {   // shading rows, in the order the trace kernel names hits: the leaves' primitives, then the `always` list
-            std::vector<uint32_t> order(builder.prims);
+        {   // shading rows, in the order the trace kernel names hits: by unit of the tree (a leaf primitive's; the rows of node
+            // units stay empty), then the `always` list
+            std::vector<uint32_t> order(builder.unit_prim);
             order.insert(order.end(), builder.always.begin(), builder.always.end());
-            std::vector<float4> rows(4 * std::max<size_t>(1, order.size()));
+            std::vector<float4> rows(4 * std::max<size_t>(1, order.size()), make_float4(0.f, 0.f, 0.f, 0.f));
             for (size_t k = 0; k < order.size(); ++k) {
                 const uint32_t id = order[k];
+                if (id == BvhBuilder::MISS_ID) continue;
                 float4 m1 = mat[4 * (size_t)id + 1];
                 m1.w = u2f(id);
                 float4 geo = id < n_sph ? sph[id] : pln[4 * (size_t)(id - n_sph)];   // sphere centre / plane normal in .xyz
@@ -823,9 +824,9 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
             if ((rc = dev_alloc(h, &h->d_shade_rows, rows.size()))) return rc;
             HIPCHK(h, hipMemcpy(h->d_shade_rows, rows.data(), rows.size() * sizeof(float4), hipMemcpyHostToDevice));
             sc.shade_rows = h->d_shade_rows;
-            sc.n_leaf_prims = (uint32_t)builder.prims.size();
+            sc.n_bvh_units = (uint32_t)builder.unit_prim.size();
         }
-        h->bvh_nodes = builder.nodes.size(); h->bvh_leaf_prims = builder.prims.size();
+        h->bvh_nodes = builder.n_nodes; h->bvh_leaf_prims = builder.n_leaf_prims;
         h->bvh_depth = (uint64_t)builder.depth4; h->bvh_binary_depth = (uint64_t)builder.max_depth_seen;
         h->bvh_forced_median_splits = builder.forced_median_splits; h->bvh_level_fold = builder.level_fold ? 1 : 0;
         h->lds_bytes = (size_t)BVH_LDS_ENTRIES * BVH_STACK_STRIDE * sizeof(uint2);
@@ -1198,8 +1199,8 @@ int ptgpu_bvh_build_stats(const PtSceneDesc *s, PtStats *out) {
     flatten_scene(s, sph, pln, mat, lights, glass);
     BvhBuilder builder;
     builder.build(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
-    out->bvh_nodes = builder.nodes.size();
-    out->bvh_leaf_prims = builder.prims.size();
+    out->bvh_nodes = builder.n_nodes;
+    out->bvh_leaf_prims = builder.n_leaf_prims;
     out->bvh_depth = (uint64_t)builder.depth4;
     out->bvh_binary_depth = (uint64_t)builder.max_depth_seen;
     out->bvh_forced_median_splits = builder.forced_median_splits;
