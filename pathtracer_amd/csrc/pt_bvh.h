@@ -62,8 +62,10 @@ constexpr uint32_t BVH_TRAV_BLOCKS = 2048;  // most blocks a traversing kernel i
 // gets (-huge, +huge) and a ray beside it is culled or not according to that sign.  Capping only ever shortens a
 // distance without changing its sign, which can keep a box that could have been culled, never the reverse (for
 // coordinates below 2^63; the cap also covers a NaN direction, whose primitive tests all fail anyway).
+// The reciprocal itself is the hardware's approximation (1 ulp): the slab test only has to be conservative, and an
+// error of 2^-23 of a distance is far inside the builder's padding.
 __device__ __forceinline__ float slab_reciprocal(float d) {
-    float r = 1.0f / d;
+    float r = __builtin_amdgcn_rcpf(d);
     return __builtin_fabsf(r) <= 0x1p64f ? r : __builtin_copysignf(0x1p64f, d);
 }
 
@@ -199,8 +201,12 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t sel, float A, flo
 // One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of the unit the lane stands on, then either the
 // four box tests of a node (nearest hit child next, the other hit children pushed with their entry distances) or the
 // test of a leaf primitive.  Returns the number of units it fetched (1).
-__device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk) {
+// `leaf_turn` (the same for every lane of the wave): whether lanes that stand on a leaf primitive take their step now.
+// The primitive test is executed by the whole wave whenever a single lane needs it; holding such lanes back until a
+// turn comes gathers them, so that the test code runs in fewer steps with more lanes each.
+__device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk, bool leaf_turn = true) {
     const bool in_leaf = s.node < 0;
+    if (in_leaf && !leaf_turn) return 0u;
     // (the shift drops bit 31; a 32-bit offset from a base all lanes share keeps the base in scalar registers)
     const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.bvh_nodes) + (size_t)((uint32_t)s.node << 6));
     float4 q0 = p[0], q1 = p[1], q2 = p[2];

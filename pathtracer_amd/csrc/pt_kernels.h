@@ -244,20 +244,27 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
 // (measured on the 1M-rectangle field).  Here waves claim CHUNKS of records from a per-level counter (one atomic per
 // wave and chunk) and a lane that finishes its ray takes the next unprocessed record of its wave's chunk (rank among
 // idle lanes by ballot + popcount), so lanes stay busy until the whole level runs dry.  Results go to
-// hitprim[record]; which lane traced a record is irrelevant.  Measured: small chunks win (2 tiles: 22.3 ms, 8 tiles:
-// 27.4 ms per 4 launches) because the launch ends when its slowest wave does; 8 steps between refill checks.
+// hitprim[record]; which lane traced a record is irrelevant.  The constants below were measured on that scene
+// (1080p, depth 4, whole job, Mrays/s) with the others at their defaults: tiles per chunk 2: 6500, 4: 6770, 8: 6600,
+// 16: 6220 (the launch ends when its slowest wave does); steps between refill checks 4: 6770, 6: 6770, 8: 6430;
+// waves per SIMD 5: 6140, 6: 6240, 7: 6430, 8: 5570; leaf turns every step: 6120, every 2nd: 6230, every 4th: 6220.
 #ifndef PT_DYN_TILES
-#define PT_DYN_TILES 2
+#define PT_DYN_TILES 4
 #endif
 #ifndef PT_DYN_STEPS
-#define PT_DYN_STEPS 8
+#define PT_DYN_STEPS 6
 #endif
 constexpr uint32_t DYN_TILES = PT_DYN_TILES;   // wave-tiles (of 64 records) per chunk
 static_assert(DYN_TILES >= 1 && DYN_TILES <= 64 && (DYN_TILES & (DYN_TILES - 1)) == 0, "a chunk's tiles are described by the first lanes of a wave");
 constexpr int DYN_STEPS = PT_DYN_STEPS;        // traversal steps between refill checks
+#ifndef PT_DYN_LEAF_EVERY
+#define PT_DYN_LEAF_EVERY 2
+#endif
+constexpr int DYN_LEAF_EVERY = PT_DYN_LEAF_EVERY;  // lanes on a leaf primitive take their step in every n-th step of the wave
+static_assert((DYN_LEAF_EVERY & (DYN_LEAF_EVERY - 1)) == 0 && DYN_STEPS % DYN_LEAF_EVERY == 0, "leaf turns must recur within a round of steps");
 
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 6  // measured on the quad field: 5 waves per SIMD (89 VGPRs) 3670, 6 (80, 52 B scratch) 3850, 7 (72, 84 B) 3180 Mrays/s
+#define PT_TRACE_WAVES 7
 #endif
 __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc, Level L, Counters *ctr) {
     __shared__ uint32_t s_incl[NSHARD], s_cnt[NSHARD];
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
                 ++n_steps; ++ray_steps;
                 if (st.node < 0) ++n_leaf;
 #endif
-                my_steps += bvh_step(sc, st, stk);
+                my_steps += bvh_step(sc, st, stk, (it & (DYN_LEAF_EVERY - 1)) == DYN_LEAF_EVERY - 1);
                 if (st.node == BVH_EMPTY) {
                     L.hitprim()[rec] = pack_hit(st.best == MISS ? MISS : st.best_slot, st.best_out);   // by shading row, not by id
                     L.hit_t()[rec] = st.best_t;
