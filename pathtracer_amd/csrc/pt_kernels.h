@@ -206,7 +206,7 @@ __device__ __forceinline__ void primary_ray(const DevScene &sc, const PassParams
     camera_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
 }
 
-// Only the two-kernel (trace, shade) pipeline stores primary rays; the fused kernel generates them in place.
+// Only the two-kernel (trace, shade) pipeline of scenes without a BVH stores primary rays; the others generate them in place.
 __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, Level L0, PassParams pp, uint32_t n_records) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_records; i += gridDim.x * BLOCK) {
         V3 o, d;
@@ -266,7 +266,10 @@ static_assert((DYN_LEAF_EVERY & (DYN_LEAF_EVERY - 1)) == 0 && DYN_STEPS % DYN_LE
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 7
 #endif
-__global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc, Level L, Counters *ctr) {
+// RAYGEN: level 0, whose rays are generated here from the record index instead of being read (the shade kernel that
+// follows generates them again: cheaper than a kernel that writes them and two that read them).
+template <bool RAYGEN>
+__global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc, Level L, PassParams pp, Counters *ctr) {
     __shared__ uint32_t s_incl[NSHARD], s_cnt[NSHARD];
     if (pass_voided(L)) return;
     TileMap m = tile_map(L);
@@ -317,8 +320,15 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
             const uint32_t base = (uint32_t)__shfl((int)tile_base, (int)((k >> 6) & (DYN_TILES - 1))), cnt = (uint32_t)__shfl((int)tile_cnt, (int)((k >> 6) & (DYN_TILES - 1)));
             if (!active && k < end && (k & 63u) < cnt) {
                 rec = base + (k & 63u);
-                float4 a = L.rayA()[rec], b = L.rayB()[rec];
-                bvh_begin(sc, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), st);
+                V3 ro, rd;
+                if (RAYGEN) {
+                    uint32_t skey;
+                    primary_ray(sc, pp, rec, ro, rd, skey);
+                } else {
+                    float4 a = L.rayA()[rec], b = L.rayB()[rec];
+                    ro = v3(a.x, a.y, a.z); rd = v3(a.w, b.x, b.y);
+                }
+                bvh_begin(sc, ro, rd, st);
                 active = true;
 #ifdef PT_TRAV_STATS
                 if (ray_steps > max_steps) max_steps = ray_steps;

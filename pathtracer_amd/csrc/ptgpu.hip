@@ -431,7 +431,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
     for (Level &L : levels) L.overflow = flag;
     k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap, flag);
-    if (!h->fused && !h->ahead) {
+    if (!h->fused && !h->ahead && !bvh) {
         Span s(h, PT_KERNEL_RAYGEN, st);
         k_raygen<<<flat_grid, BLOCK, 0, st>>>(sc, levels[0], pp, S);
     }
@@ -475,11 +475,13 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         } else {
             {
                 Span s(h, PT_KERNEL_TRACE, st);
-                if (sc.bvh_nodes) k_trace_dyn<<<TG, BLOCK, lds, st>>>(sc, L, h->d_ctr);
+                if (bvh && l == 0) k_trace_dyn<true><<<TG, BLOCK, lds, st>>>(sc, L, pp, h->d_ctr);
+                else if (bvh) k_trace_dyn<false><<<TG, BLOCK, lds, st>>>(sc, L, pp, h->d_ctr);
                 else k_trace<<<TG, BLOCK, lds, st>>>(sc, L);
             }
             Span s(h, PT_KERNEL_SHADE, st);
-            if (bvh) k_shade<false, false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);   // hits named by shading row
+            if (bvh && l == 0) k_shade<false, true, false, true><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);   // hits named by shading row
+            else if (bvh) k_shade<false, false, false, true><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
             else if (h->lds_scene) k_shade<false, false, true, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
             else k_shade<false, false, false, false><<<GRID_TILES, BLOCK, 0, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
         }
