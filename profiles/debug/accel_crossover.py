@@ -1,20 +1,21 @@
-"""Linear scan against BVH on the closed diffuse room with N spheres: where the library's automatic choice should switch."""
-import sys, time
-sys.path.insert(0, ".")
-from pathtracer_amd import binding, scene as S
+"""Diagnostic: where the BVH pipeline overtakes the fused linear scan.  The closed room (1080p, depth 8) with N spheres,
+rendered with the acceleration structure forced off and on.  Usage (GPU box): python profiles/debug/accel_crossover.py"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pathtracer_amd import binding as B, scene as S
 
-for n in (20, 40, 60, 80, 120, 160):
+for n in (20, 50, 80, 110, 140, 170, 230):
     sc = S.diffuse_room_scene(1920, 1080, n_spheres=n)
-    row = []
-    for accel in (1, 2):
-        with binding.PtGpu(accel=accel, max_depth=8) as gpu:
-            gpu.upload_scene(sc)
-            gpu.render(16)
-            gpu.sync()
-            gpu.clear()
+    out = []
+    for accel in (1, 2):   # PT_ACCEL_LINEAR, PT_ACCEL_BVH
+        with B.PtGpu(max_depth=8, accel=accel) as g:
+            g.upload_scene(sc)
+            g.render(32); g.sync()
+            r0 = g.stats()["rays"]
             t = time.perf_counter()
-            gpu.render(64)
-            gpu.sync()
+            g.render(128); g.sync()
             dt = time.perf_counter() - t
-            row.append(gpu.stats()["rays"] / dt / 1e9)
-    print(f"{n + 7:4d} primitives: linear scan {row[0]:6.2f} Grays/s   BVH {row[1]:6.2f} Grays/s", flush=True)
+            out.append((g.stats()["rays"] - r0) / dt / 1e9)
+    print(f"{n + 7} primitives: linear scan {out[0]:.2f} Grays/s, BVH {out[1]:.2f} Grays/s", flush=True)
