@@ -134,7 +134,7 @@ def main() -> None:
                          "room: closed diffuse room at max_depth 16 (queue compaction)")
     ap.add_argument("--grid", type=int, default=1000, help="quads: rectangles per side")
     ap.add_argument("--fused", type=int, default=-1)
-    ap.add_argument("--accel", type=int, default=0, help="0 = library choice (BVH above 192 primitives), 1 = linear scan, 2 = BVH")
+    ap.add_argument("--accel", type=int, default=0, help="0 = library choice (BVH above 100 primitives), 1 = linear scan, 2 = BVH")
     ap.add_argument("--batch", type=int, default=0, help="samples per pixel per pipeline pass (0 = library default)")
     ap.add_argument("--passes", type=int, default=-1,
                     help="pipeline passes in flight; 0 = library default (2); -1 = 1, so that the per-kernel durations of the "

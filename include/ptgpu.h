@@ -129,7 +129,7 @@ typedef struct {
     uint64_t records;                         /* queue records processed over all levels since clear */
     uint64_t terminal_records;                /* the part of `records` on the last level (terminal light samples that need a shadow ray) */
     uint64_t bvh_nodes, bvh_leaf_prims;       /* size of the current BVH (0 for brute force) */
-    uint64_t bvh_steps;                       /* 64-byte units fetched by the BVH trace kernel since clear: 2 per inner node (128 bytes), 1 per leaf primitive */
+    uint64_t bvh_steps;                       /* 64-byte units of the tree fetched by the BVH trace kernel since clear: 1 per node, 1 per leaf primitive */
     uint64_t kernel_launches[PT_KERNEL_COUNT];/* since clear (profile_events only) */
     double kernel_ms[PT_KERNEL_COUNT];        /* since clear (profile_events only) */
     uint64_t device_bytes;                    /* device memory held by the handle */
