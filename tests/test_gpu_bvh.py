@@ -234,3 +234,63 @@ def test_skewed_tree_is_refolded_and_traversed_exactly(binding, oracle):
     assert np.array_equal(ids_b[0], osc.primary_ids(oracle.options(), 0))
     assert np.array_equal(p_b, osc.render(oracle.options(), 3)[0])
     assert len(np.unique(ids_b[0])) > 5   # spheres of several sizes, the light or the sky are seen
+
+
+# ---- boxes on an 8-bit grid per node: sizes over five decades, far from the coordinate origin -------------------------
+def clutter_scene(seed, n_planes=2500, n_spheres=1500, width=160, height=90, centre=(5000.0, -3000.0, 2000.0)):
+    """Randomly oriented rectangles (u, v NOT perpendicular in general, so their acceptance region is the slab
+    intersection, not the parallelogram) and spheres with sizes log-uniform over 1e-2 .. 1e3 in a 400-unit cloud whose
+    centre lies thousands of units from the origin: the grid origins of the tree's nodes are large numbers and a node's
+    cell size varies by orders of magnitude between siblings' subtrees.  The camera sits inside the cloud; a light faces it."""
+    rng = np.random.RandomState(seed)
+    c = np.asarray(centre)
+    sc = S.Scene(image_settings=S.ImageSettings(width, height, True),
+                 camera=S.Camera(tuple(c + (0.0, 0.0, 120.0)), tuple(c), (0.0, 1.0, 0.0), 9.0 * width / height, 9.0, 10.0,
+                                 S.TONE_CLAMP, 1.0, 100.0),
+                 sky=S.Sky.constant((0.4, 0.5, 0.6)))
+    size = 10.0 ** rng.uniform(-2.0, 3.0, n_planes)
+    u = rng.normal(size=(n_planes, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(size=(n_planes, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    planes = np.zeros(n_planes, dtype=S.PLANE_DT)
+    planes["u"] = (u * size[:, None]).astype(np.float32)
+    planes["v"] = (v * (size * rng.uniform(0.2, 1.0, n_planes))[:, None]).astype(np.float32)
+    planes["origin"] = (c + rng.uniform(-200.0, 200.0, (n_planes, 3))).astype(np.float32)
+    planes["material"]["kind"] = S.MAT_PHYSICALLY
+    planes["material"]["color"] = rng.uniform(0.2, 1.0, (n_planes, 3)).astype(np.float32)
+    planes["material"]["roughness"] = rng.uniform(0.0, 1.0, n_planes).astype(np.float32)
+    planes["material"]["metalness"] = (rng.uniform(0.0, 1.0, n_planes) < 0.2).astype(np.float32)
+    planes["material"]["ior"] = 1.0
+    sc.planes = planes
+    spheres = np.zeros(n_spheres, dtype=S.SPHERE_DT)
+    spheres["radius"] = (10.0 ** rng.uniform(-2.0, 1.5, n_spheres)).astype(np.float32)
+    spheres["origin"] = (c + rng.uniform(-200.0, 200.0, (n_spheres, 3))).astype(np.float32)
+    spheres["material"]["kind"] = np.where(rng.uniform(0.0, 1.0, n_spheres) < 0.1, S.MAT_TRANSLUCENT, S.MAT_PHYSICALLY)
+    spheres["material"]["color"] = rng.uniform(0.2, 1.0, (n_spheres, 3)).astype(np.float32)
+    spheres["material"]["roughness"] = rng.uniform(0.0, 1.0, n_spheres).astype(np.float32)
+    spheres["material"]["ior"] = 1.5
+    sc.spheres = spheres
+    sc.add(S.Plane(tuple(c + (-150.0, 250.0, -150.0)), (300.0, 0.0, 0.0), (0.0, 0.0, 300.0), S.Material.emissive((8.0, 8.0, 8.0))))
+    return sc
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_clutter_bvh_equals_linear_scan_and_oracle(binding, oracle, seed):
+    sc = clutter_scene(seed)
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 3, max_depth=5)
+    ids_l, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 3, max_depth=5)
+    # (a few rectangles with nearly parallel edges cannot be bounded and are tested for every ray)
+    assert 3980 <= st_b["bvh_leaf_prims"] <= 4001 and (ids_b[0] != 0xFFFFFFFF).mean() > 0.5
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_b, p_l) and st_b["rays"] == st_l["rays"]
+    small = clutter_scene(seed, width=48, height=27)
+    osc = oracle.OracleScene(small)
+    with binding.PtGpu(accel=binding.ACCEL_BVH, max_depth=5) as gpu:
+        gpu.upload_scene(small)
+        ids = gpu.primary_ids(1)
+        gpu.render(2)
+        p32, _ = gpu.read_pixels32()
+        rays = gpu.stats()["rays"]
+    assert np.array_equal(ids, osc.primary_ids(oracle.options(max_depth=5), 1))
+    r32, _, r_rays = osc.render(oracle.options(max_depth=5), 2)
+    assert np.array_equal(p32, r32) and rays == r_rays
