@@ -310,13 +310,16 @@ __global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t sha
 
 uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
 
-// auto: two passes in flight.  BVH scenes: a launch ends with a few rays that walk hundreds of nodes on an otherwise
-// idle GPU and the other pass fills that tail (+50 % at 8 spp per pass on the 1M-rectangle field).  Small scenes: the
-// forward kernels are bound by arithmetic and latency, the backward sweep by HBM bandwidth, and one pass's sweep
-// runs under the other's forward kernels (+7.5 % on the sample scene, +5 % on the room; a third pass adds nothing).
+// auto.  Small scenes: two passes in flight - the forward kernels are bound by arithmetic and latency, the backward
+// sweep by HBM bandwidth, and one pass's sweep runs under the other's forward kernels (+4-7 % on the sample scene, +5 %
+// on the room; a third pass adds nothing).  BVH scenes: ONE pass of twice the size - a launch of the trace kernel ends
+// with a few rays that walk hundreds of nodes on an otherwise idle GPU, and a longer launch dilutes that tail better
+// than a second pass fills it (1M-rectangle field at 1080p: one pass of 64 spp 7 180 Mrays/s, one of 32 spp 6 800, two
+// of 32 spp 6 670).
 int pipes_wanted(const PtHandle *h) {
     const uint32_t c = h->cfg.concurrent_passes;
-    return c == 0 ? 2 : (int)std::min<uint32_t>(c, PT_MAX_PIPES);
+    if (c == 0) return h->sc.bvh_nodes ? 1 : 2;
+    return (int)std::min<uint32_t>(c, PT_MAX_PIPES);
 }
 
 int alloc_levels(PtHandle *h) {
@@ -330,14 +333,16 @@ int alloc_levels(PtHandle *h) {
     // (measured on the sample scene at 1080p, one pass in flight: 8M records 24.1, 16M 25.3, 32M 26.3, 64M 27.8 Grays/s -
     // every kernel boundary drains the chip once; with two passes in flight the steps are 28.4 / 28.7 / 29.0.  BVH
     // scenes gain more: a launch ends with a few rays that walk hundreds of nodes and longer launches dilute that)
-    const uint64_t target = 64u << 20;
-    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target / std::max<uint32_t>(P, 1)));
+    const uint64_t target = (h->sc.bvh_nodes ? 128u : 64u) << 20;   // (halved below when two such passes exceed the budget)
+    if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(h->sc.bvh_nodes ? 128 : 64, target / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
     const uint64_t rec_bytes = Level::RECORD_BYTES;
-    const uint64_t budget = 48ull << 30;  // of the 288 GB of an MI355X, over all passes in flight
+    const uint64_t budget = 52ull << 30;  // of the 288 GB of an MI355X, over all passes in flight (the estimate below counts
+                                          // every level at full size: 49.4 GiB for 128M level-0 records at depth 4, of which
+                                          // 47.5 GiB are allocated)
     for (;;) {
         uint64_t total = 0;
         for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4 * pipes_wanted(h);
