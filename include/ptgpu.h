@@ -112,7 +112,7 @@ typedef struct {
                                      their children; leaf children never become records); -1: auto (BVH scenes 0, others 1) */
     int32_t profile_events;       /* 1: bracket kernels with HIP events and report per-kernel time in PtStats */
     uint32_t concurrent_passes;   /* 1..4 pipeline passes in flight (own queues and HIP stream each; one fills the GPU while
-                                     another drains its last long rays or sweeps backward); 0 = auto (2) */
+                                     another drains its last long rays or sweeps backward); 0 = auto (2; BVH scenes: 1 pass of twice the size) */
     int32_t camera_model;         /* 0: CameraSampler::pinhole_ray (what the reference renders with, tracer.rs:629);
                                      1: CameraSampler::thin_lens_ray (tracer.rs:144-197, unused there) */
     float focus_distance;         /* thin lens: FOCUS_DISTANCE, reference constant 10.0 (tracer.rs:155) */
