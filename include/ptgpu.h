@@ -211,7 +211,9 @@ int ptgpu_stream(PtHandle *h, void **stream);
 int ptgpu_get_stats(PtHandle *h, PtStats *out);
 /* The acceleration structure ptgpu_upload_scene would build for this scene, built on the host only (no device is
  * touched): fills the bvh_* fields of *out, zeroes the rest.  The reference has no such structure (find_scene_hit,
- * src/scene.rs:263-297, scans every primitive); this is how a host or a test checks its size and depth bounds. */
+ * src/scene.rs:263-297, scans every primitive); this is how a host or a test checks its size and depth bounds.  The
+ * structure is also checked against itself - every primitive inside the box of every node above it, each reachable
+ * exactly once -: PT_ERR_INTERNAL if that fails. */
 int ptgpu_bvh_build_stats(const PtSceneDesc *scene, PtStats *out);
 const char *ptgpu_last_error(PtHandle *h);
 

@@ -328,6 +328,50 @@ struct BvhBuilder {
         return n;
     }
 
+    // Self check of the device image: walks the units the way the traversal addresses them and counts (a) children whose
+    // box, decoded exactly as origin + q * 2^e, does not contain the padded box of every primitive below them - such a
+    // primitive could be skipped by a ray that hits it -, and (b) boundable primitives that are not reachable exactly once.
+    uint64_t check() const {
+        uint64_t bad = 0, seen = 0;
+        struct FBox { double lo[3], hi[3]; };
+        auto rec = [&](auto &&self, uint32_t unit, int depth) -> FBox {
+            FBox all;
+            for (int d = 0; d < 3; ++d) { all.lo[d] = 1e300; all.hi[d] = -1e300; }
+            if (depth > BVH_STACK || (size_t)unit >= unit_prim.size() || unit_prim[unit] != MISS_ID) { ++bad; return all; }
+            uint32_t w[16];
+            std::memcpy(w, &units[4 * (size_t)unit], 64);
+            float org[3];
+            std::memcpy(org, w, 12);
+            for (int j = 0; j < 4; ++j) {
+                int qlo[3], qhi[3];
+                bool exists = true;
+                for (int d = 0; d < 3; ++d) {
+                    const uint32_t pair = (w[4 + 2 * d + j / 2] >> (16 * (j % 2))) & 0xffffu;
+                    qlo[d] = (int)(pair & 0xffu); qhi[d] = (int)(pair >> 8);
+                    if (qlo[d] > qhi[d]) exists = false;
+                }
+                if (!exists) continue;
+                const uint32_t child = w[10] + (uint32_t)j;
+                FBox sub;
+                if ((w[3] >> (24 + j)) & 1u) {
+                    if ((size_t)child >= unit_prim.size() || unit_prim[child] == MISS_ID) { ++bad; continue; }
+                    const Box &b = pbox[unit_prim[child]];
+                    for (int d = 0; d < 3; ++d) { sub.lo[d] = down(b.lo[d] - pad); sub.hi[d] = up(b.hi[d] + pad); }
+                    ++seen;
+                } else sub = self(self, child, depth + 1);
+                for (int d = 0; d < 3; ++d) {
+                    const double cell = std::ldexp(1.0, (int)(int8_t)((w[3] >> (8 * d)) & 0xffu));
+                    if (sub.lo[d] < (double)org[d] + qlo[d] * cell || sub.hi[d] > (double)org[d] + qhi[d] * cell) { ++bad; break; }
+                }
+                for (int d = 0; d < 3; ++d) { all.lo[d] = std::min(all.lo[d], sub.lo[d]); all.hi[d] = std::max(all.hi[d], sub.hi[d]); }
+            }
+            return all;
+        };
+        if (!unit_prim.empty()) rec(rec, 0u, 0);
+        if (seen != idx.size() || seen != n_leaf_prims) ++bad;
+        return bad;
+    }
+
     void flatten() {
         // Unit 0 is the root.  A node's children get a run of consecutive units when the node is written; nodes are
         // written depth first, so a subtree's units stay close together and rays that are close in space share cache

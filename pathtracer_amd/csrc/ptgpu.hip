@@ -1213,7 +1213,8 @@ int ptgpu_bvh_build_stats(const PtSceneDesc *s, PtStats *out) {
     out->bvh_binary_depth = (uint64_t)builder.max_depth_seen;
     out->bvh_forced_median_splits = builder.forced_median_splits;
     out->bvh_level_fold = builder.level_fold ? 1 : 0;
-    return PT_OK;
+    // every primitive inside the (quantised) box of every node above it, each reachable exactly once
+    return builder.check() == 0 ? PT_OK : PT_ERR_INTERNAL;
     PT_API_END(nullptr)
 }
 

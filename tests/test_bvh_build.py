@@ -36,3 +36,18 @@ def test_degenerate_inputs(binding):
     sc.spheres = sp
     st = binding.bvh_build_stats(sc)
     assert st["bvh_leaf_prims"] == 5000 and 3 * st["bvh_depth"] <= BVH_STACK
+
+
+def test_every_primitive_lies_inside_every_box_above_it(binding):
+    """ptgpu_bvh_build_stats walks the device image of the tree it built and fails with PT_ERR_INTERNAL when a node's box
+    for a child (8-bit grid, decoded as origin + q * 2^e) does not contain the padded box of every primitive below it, or
+    when a boundable primitive is not reachable exactly once (binding.bvh_build_stats raises then).  Here: the full
+    1M-rectangle field, clutter over five decades of size thousands of units from the origin, spheres over 36 decades,
+    coincident primitives, and flat boxes (axis-aligned rectangles have no extent along their normal)."""
+    from test_gpu_bvh import clutter_scene
+    assert binding.bvh_build_stats(S.quad_field_scene(64, 36))["bvh_leaf_prims"] == 1000 * 1000 + 1000 + 1
+    for seed in (1, 2, 3, 4, 5):
+        assert binding.bvh_build_stats(clutter_scene(seed, n_planes=20000, n_spheres=10000))["bvh_leaf_prims"] > 29800
+    assert binding.bvh_build_stats(skewed_spheres_scene(1000))["bvh_leaf_prims"] == 1001
+    assert binding.bvh_build_stats(S.sample_scene(32, 32))["bvh_leaf_prims"] == 10
+    assert binding.bvh_build_stats(S.diffuse_room_scene(32, 32, n_spheres=300))["bvh_leaf_prims"] == 307
