@@ -20,7 +20,8 @@ def test_skewed_tree_hits_the_depth_cap_and_is_refolded(binding):
         st = binding.bvh_build_stats(skewed_spheres_scene(n))
         assert st["bvh_binary_depth"] == 38, st            # the cap of the binary tree
         assert st["bvh_forced_median_splits"] > 0, st      # ... held by median splits
-        assert st["bvh_level_fold"] == 1, st               # folding by area would have been too deep for the stack
+        assert st["bvh_level_fold"] == (1 if n >= 300 else 0), st   # folding by area would have been too deep for the stack (at 100
+                                                                    # spheres the candidate tree that is kept folds to 15 levels)
         assert 3 * st["bvh_depth"] <= BVH_STACK, st
         assert st["bvh_leaf_prims"] == n + 1
 
