@@ -155,7 +155,7 @@ def test_full_field_bvh_shape(binding):
         gpu.upload_scene(_full_field(64, 36))
         st = gpu.stats()
     assert st["bvh_leaf_prims"] == 1_001_001
-    assert 480_000 < st["bvh_nodes"] < 560_000       # 4-wide nodes over a binary tree of 1M leaves
+    assert 333_667 <= st["bvh_nodes"] < 560_000      # 4-wide nodes over 1M leaves: at least (n - 1) / 3, were every node full
     # the field is regular enough that binned SAH stays balanced: no forced median split, folded by box area
     assert st["bvh_binary_depth"] <= 30 and st["bvh_forced_median_splits"] == 0 and st["bvh_level_fold"] == 0
     assert 3 * st["bvh_depth"] <= 64                 # the traversal stack's bound
