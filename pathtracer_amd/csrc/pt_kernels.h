@@ -169,10 +169,10 @@ typedef const f4_t __attribute__((address_space(4))) *const_f4_ptr;
 // `transition`: the winner's Transition (0 In, 1 Out: a sphere left from inside).  BVH is a compile-time choice:
 // kernels for scenes without one carry no traversal code - with it inlined the fused kernel needs 117 instead of 89-95
 // registers (4 instead of 5 waves per SIMD: measured 20.4 vs 22.1 Grays/s on the sample scene).
-template <bool BVH>
+template <bool BVH, bool DEFER = false>
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t, int &transition) {
     if (BVH) return bvh_nearest(sc, o, d, t, transition);
-    return nearest_brute((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
+    return nearest_brute<DEFER>((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
 }
 template <bool BVH>
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t) {
@@ -499,8 +499,9 @@ __host__ __device__ inline bool lds_scene_fits(uint32_t n_sph, uint32_t n_pl) { 
 
 // Wave-granular kernel: each wave takes 64 consecutive records.  FUSED: intersection here as well; RAYGEN: level 0
 // generates its primary rays in place; LDS_SCENE: see above (the host checks lds_scene_fits).  BVH without FUSED: the
-// hits were left by k_trace_dyn, which names them by shading row (DevScene::shade_rows).
-template <bool FUSED, bool RAYGEN, bool LDS_SCENE, bool BVH>
+// hits were left by k_trace_dyn, which names them by shading row (DevScene::shade_rows).  DEFER: the linear scan tests
+// the spheres that survive its cheap rejections lane by lane (scenes with more than DEFER_SPHERES spheres).
+template <bool FUSED, bool RAYGEN, bool LDS_SCENE, bool BVH, bool DEFER = false>
 __global__ __launch_bounds__(BLOCK, (BVH && FUSED) ? 4 : PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, (BVH && FUSED) ? 4 : PT_SHADE_WAVES) void k_
             // primary rays of a linear-scan scene: a wave none of whose rays can reach the scene's box skips the scan
             const bool reach = !(RAYGEN && !BVH) || !sc.has_bounds || may_reach_box(sc.bounds_lo, sc.bounds_hi, o, d);
             if (FUSED) {
-                if (!(RAYGEN && !BVH) || __ballot(reach) != 0ull) prim = nearest_hit<BVH>(sc, o, d, hit_t, hit_tr);
+                if (!(RAYGEN && !BVH) || __ballot(reach) != 0ull) prim = nearest_hit<BVH, DEFER>(sc, o, d, hit_t, hit_tr);
             } else {  // the trace kernel left the winner, its Transition and its distance
                 uint32_t word = L.hitprim()[i];
                 hit_t = L.hit_t()[i];

@@ -89,6 +89,17 @@ PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t, int &out) {
 }
 template <class T4>
 PT_HD bool sphere_test(T4 sp, V3 p, V3 d, float &t) { int out; return sphere_test(sp, p, d, t, out); }
+// The first two rejections of sphere_test alone (the same operations on the same operands): false = certainly no hit.
+template <class T4>
+PT_HD bool sphere_may_hit(T4 sp, V3 p, V3 d) {
+    V3 s = v3(sp.x, sp.y, sp.z);
+    float r = sp.w;
+    V3 c = s - p;
+    float e_len = dot(d, c);
+    if (e_len < -r) return false;
+    V3 v = e_len * d - c;
+    return !(dot(v, v) > (r * r) * 1.000002f);
+}
 // Full hit record of a sphere already known to be hit.
 PT_HD bool sphere_hit(float4 sp, V3 p, V3 d, Hit &h) {
     V3 s = v3(sp.x, sp.y, sp.z);
@@ -209,12 +220,42 @@ inline uint32_t plane_axis_code(V3 n, V3 s, V3 un, float ul, V3 vn, float vl, bo
 // A later primitive replaces the current nearest only when strictly closer.  P4 is any pointer to a 4-float
 // vector (the kernels pass constant-address-space pointers so the wave-uniform primitive fetches become
 // scalar loads into SGPRs).
-template <class P4>
+// DEFER (device only, a kernel-level choice for scenes with more than DEFER_SPHERES spheres): see below.
+constexpr uint32_t DEFER_SPHERES = 8;
+template <bool DEFER = false, class P4>
 PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p, V3 d, float &best_t, int &best_out) {
     uint32_t best = MISS;
     best_t = 0.0f;
     best_out = 0;  // Transition of the winner (planes are only ever accepted as In)
-    for (uint32_t i = 0; i < n_sph; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Every sphere's cheap rejections first, for all lanes at once; what survives (a few per cent of the lanes per
+    // sphere) is then tested in full lane by lane, each lane on ITS next candidate: the square roots run once or twice per
+    // wave instead of once per sphere that any lane might hit.  A lane takes its candidates in ascending order and
+    // replaces only when strictly closer, as the scan over all spheres does.  Measured at 1080p: the room with 20
+    // spheres +4 %, the sample scene with 3 spheres -3 % (the bookkeeping and the per-lane fetch cost more than two
+    // skipped rounds of roots save), hence the threshold - and a template parameter, because the mere presence of this
+    // loop in the sample scene's kernel costs it 0.5 %.
+    const bool deferred = DEFER;
+    for (uint32_t first = 0; deferred && first < n_sph; first += 32u) {
+        const uint32_t n = n_sph - first < 32u ? n_sph - first : 32u;
+        uint32_t cand = 0;
+        for (uint32_t i = 0; i < n; ++i) cand |= sphere_may_hit(sph[first + i], p, d) ? 1u << i : 0u;
+        while (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const uint32_t i = first + (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                float t;
+                int out;
+                if (sphere_test(sph[i], p, d, t, out)) {
+                    if (best == MISS || t < best_t) { best = i; best_t = t; best_out = out; }
+                }
+            }
+        }
+    }
+#else
+    const bool deferred = false;
+#endif
+    for (uint32_t i = 0; !deferred && i < n_sph; ++i) {
         float t;
         int out;
         if (sphere_test(sph[i], p, d, t, out)) {

@@ -469,6 +469,9 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
                 if (bvh) {  // (lds_scene is off with a BVH)
                     if (l == 0) k_shade<true, true, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
                     else k_shade<true, false, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
+                } else if (h->lds_scene && sc.n_sph > DEFER_SPHERES) {   // many spheres: their full tests lane by lane (nearest_brute)
+                    if (l == 0) k_shade<true, true, true, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
+                    else k_shade<true, false, true, false, true><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);
                 } else if (h->lds_scene) {
                     if (l == 0) k_shade<true, true, true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, 0u, last, h->d_ctr);
                     else k_shade<true, false, true, false><<<TG, BLOCK, lds, st>>>(sc, L, Lp, Ln, pp, (uint32_t)l, last, h->d_ctr);

@@ -428,6 +428,24 @@ def test_silhouettes_on_the_faces_of_the_scene_box(binding, oracle, jitter):
         assert np.array_equal(p32, r32) and np.array_equal(p8, r8) and st["rays"] == rays, len(prims)
 
 
+# ---- linear scan over many spheres: the full tests run lane by lane on each lane's own candidates -------------------
+@pytest.mark.parametrize("n_spheres", [9, 33, 80])
+def test_many_spheres_linear_scan(binding, oracle, n_spheres):
+    """More than eight spheres switch the fused kernels to the deferred sphere tests (candidates kept in a 32-bit mask per
+    lane, so 33 and 80 spheres also cross a chunk boundary); with at most 100 primitives the scene stays on the linear scan.
+    Overlapping spheres give lanes several candidates, glass ones rays that start inside a sphere."""
+    sc = S.diffuse_room_scene(96, 54, n_spheres=n_spheres, seed=n_spheres)
+    for k, sp in enumerate(sc.spheres):
+        if k % 3 == 0:
+            sp.radius *= 2.5                               # overlaps
+        if k % 4 == 1:
+            sp.material = S.Material.translucent(1.5)
+    p32, p8, ns, st = _gpu_render(binding, sc, 3, max_depth=6)
+    assert st["bvh_nodes"] == 0
+    _, _, (r32, r8, rays) = _oracle_render(oracle, sc, 3, max_depth=6)
+    assert np.array_equal(p32, r32) and np.array_equal(p8, r8) and st["rays"] == rays
+
+
 def test_present_gives_the_display_bytes(binding):
     """The window loop's per-frame readback (Backbuffer.pixels8, src/window.rs:205-210) through the library's own
     page-locked buffer: the same bytes as ptgpu_read_pixels8, frame after frame and after a new scene of another size."""
