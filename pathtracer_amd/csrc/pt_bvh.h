@@ -211,6 +211,7 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
     const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.bvh_nodes) + (size_t)((uint32_t)s.node << 6));
     float4 q0 = p[0], q1 = p[1], q2 = p[2];
     float4 q3;
+    q3.x = 0.0f;   // (named by the statement below for every lane)
     if (in_leaf) q3 = p[3];
     // The whole unit is requested here, in one round trip.  Without this (empty) statement that names the last vector,
     // the compiler moves its load down into the leaf arm, behind the box tests: a second round trip per step.

@@ -128,7 +128,7 @@ __device__ __forceinline__ Reservation wave_reserve(const Level &L, uint32_t sha
 }
 
 __device__ __forceinline__ void wave_resolve(const Level &L, uint32_t shard, const Reservation &r, bool &has0, bool &has1, uint32_t &i0,
-                                             uint32_t &i1, Counters *ctr) {
+                                             uint32_t &i1, Counters * /*ctr*/) {
     uint32_t n0 = (uint32_t)__popcll(r.m0), n1 = (uint32_t)__popcll(r.m1), total = n0 + n1;
     i0 = i1 = 0;
     if (total == 0) return;

@@ -447,7 +447,6 @@ PT_HD void shade_prepare(const DevScene &sc, V3 origin, V3 direction, uint32_t p
         return;
     }
     const float SHIFT_AMOUNT = 0.0001f;  // :495
-    const float R = 0.04f;               // :499
     if (!ROWS) {
         c.m0 = sc.mat[4 * prim];
         c.m1 = sc.mat[4 * prim + 1];
@@ -517,7 +516,6 @@ PT_HD void shade_finish(const ShadeCtx &c, V3 direction, uint32_t node_key, Node
         // still performs exactly the operations of its own arm (importance_sample_ggx / importance_sample_cos).
         const bool spec = c.kind == NK_SPECULAR;
         float roughness = c.m1.x;
-        V3 color = v3(c.m0.y, c.m0.z, c.m0.w);
         Basis ts = construct_coordinate_system(hit.normal);
         float xi_x = random32(rng_draw(node_key, 0));
         float xi_y = random32(rng_draw(node_key, 1));
