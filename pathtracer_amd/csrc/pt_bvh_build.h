@@ -98,18 +98,25 @@ struct BvhBuilder {
             depth4 = 1;
             return;
         }
-        // The greedy surface-area heuristic is a noisy guide here (one primitive per leaf, four children per node): on
-        // the 1M-rectangle field 2 bins per axis give 6 % fewer traversal steps than 16 and 14 % fewer than 32, on a
-        // room with 300 spheres 4 and 32 bins beat 2 and 16 by 6 %, on random clutter 32 bins win.  So several binary
-        // trees are built (concurrently) and the one whose 4-wide fold promises the fewest steps is kept; the
-        // estimate ranks them as the measured step counts do (field: 12.9 / 13.0 / 13.5 / 14.3 estimated for
-        // 2 / 4 / 16 / 32 bins, 16.8 / 17.0 / 17.9 / 19.5 measured).  Any of them gives the same image.
-        static const int CANDIDATE_BINS[] = {2, 4, 16, 32};
+        // The greedy surface-area heuristic is a noisy guide here (one primitive per leaf, four children per node): which
+        // resolution of the binning and which weight of a side's primitive count (the classic cost area * count assumes a
+        // subtree costs in proportion to its primitives; with one primitive per leaf it grows more slowly) give the tree
+        // with the fewest traversal steps differs from scene to scene - on the 1M-rectangle field 2 bins per axis give 6 %
+        // fewer steps than 16 and 14 % fewer than 32, on rooms with 120-300 spheres and on random clutter 32 bins with
+        // count^0.5 or count^0.75 beat every count^1 tree by 1-6 %.  So several binary trees are built (concurrently)
+        // and the one whose 4-wide fold promises the fewest steps is kept; the estimate ranks them as the measured step
+        // counts do (field: 12.9 / 13.0 / 13.5 / 14.3 estimated for 2 / 4 / 16 / 32 bins folded greedily, 16.8 / 17.0 /
+        // 17.9 / 19.5 measured).  Any of them gives the same image.
+#ifndef PT_CAND
+#define PT_CAND {2, 3}, {16, 3}, {32, 3}, {32, 2}
+#endif
+        struct Cand { int bins, quarter_powers; };   // side weight = count^(quarter_powers / 4)
+        static const Cand CANDIDATE_BINS[] = {PT_CAND};
         constexpr int NC = (int)(sizeof CANDIDATE_BINS / sizeof CANDIDATE_BINS[0]);
         std::vector<Tree> trees(NC);
         auto grow_tree = [&, this](int k) {
             Tree &t = trees[k];
-            t.bins = CANDIDATE_BINS[k];
+            t.bins = CANDIDATE_BINS[k].bins; t.quarter_powers = CANDIDATE_BINS[k].quarter_powers;
             t.idx = idx;
             t.bn.reserve(2 * idx.size());
             const double t0 = ms_since();
@@ -131,7 +138,7 @@ struct BvhBuilder {
         for (int k = 1; k < NC; ++k) if (trees[k].steps < trees[keep].steps) keep = k;
         if (verbose)
             for (int k = 0; k < NC; ++k)
-                std::fprintf(stderr, "bvh: %2d bins: estimate %.3f steps, depth %d%s\n", trees[k].bins, trees[k].steps, trees[k].max_depth, k == keep ? " (kept)" : "");
+                std::fprintf(stderr, "bvh: %2d bins, count^%.2f: estimate %.3f steps, depth %d%s\n", trees[k].bins, trees[k].quarter_powers / 4.0, trees[k].steps, trees[k].max_depth, k == keep ? " (kept)" : "");
         if (verbose) std::fprintf(stderr, "bvh: trees %.0f ms\n", ms_since());
         bn = std::move(trees[keep].bn);
         idx = std::move(trees[keep].idx);
@@ -217,11 +224,15 @@ struct BvhBuilder {
     struct Tree {
         std::vector<BuildNode> bn;
         std::vector<uint32_t> idx;
-        int max_depth = 0, bins = 16;
+        int max_depth = 0, bins = 16, quarter_powers = 4;
         uint64_t forced = 0;
         double steps = 0.0;
     };
     static constexpr int MAX_BINS = 32;
+    static double side_weight(uint32_t count, int quarter_powers) {   // count^(quarter_powers / 4) for 2, 3 and 4 quarters
+        const double c = (double)count, r = std::sqrt(c);
+        return quarter_powers >= 4 ? c : (quarter_powers == 3 ? r * std::sqrt(r) : r);
+    }
 
     int32_t build_range(Tree &t, uint32_t first, uint32_t count, int depth) const {
         std::vector<BuildNode> &bn = t.bn;
@@ -268,7 +279,7 @@ struct BvhBuilder {
                 for (int b = 0; b < NB - 1; ++b) {
                     acc.grow(bb[b]); cnt += bc[b];
                     if (cnt == 0 || right_cnt[b + 1] == 0) continue;
-                    double cost = acc.area() * cnt + right_area[b + 1] * right_cnt[b + 1];
+                    double cost = acc.area() * side_weight(cnt, t.quarter_powers) + right_area[b + 1] * side_weight(right_cnt[b + 1], t.quarter_powers);
                     if (cost < best_cost) { best_cost = cost; best_axis = d; best_bin = b; }
                 }
             }

@@ -796,8 +796,8 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     // ---- acceleration structure
     // Automatic choice: the fused linear-scan kernels stay ahead of the BVH pipeline (separate trace kernel, dependent
     // node fetches) up to about 100 primitives - measured on the closed room with N spheres at 1080p, depth 8
-    // (profiles/debug/accel_crossover.py): 27 primitives 21.9 vs 12.2 Grays/s, 87: 11.5 vs 10.5, 117: 9.5 vs 10.3,
-    // 177: 7.0 vs 9.2, 237: 5.6 vs 9.1.
+    // (profiles/debug/accel_crossover.py): 27 primitives 23.0 vs 12.8 Grays/s, 87: 12.6 vs 11.1, 117: 10.4 vs 10.6,
+    // 177: 7.6 vs 10.3, 237: 5.6 vs 9.9.
     bool want_bvh = h->cfg.accel == PT_ACCEL_BVH || (h->cfg.accel == PT_ACCEL_AUTO && n_sph + n_pl > 100);
     h->bvh_nodes = h->bvh_leaf_prims = 0;
     h->bvh_depth = h->bvh_binary_depth = h->bvh_forced_median_splits = h->bvh_level_fold = 0;
