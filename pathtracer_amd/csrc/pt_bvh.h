@@ -43,9 +43,11 @@ constexpr int BVH_BINARY_DEPTH = 38;   // depth cap of the binary tree the build
 constexpr int BVH_STACK = 64;          // entries per lane: a step pushes up to 3 per level of the 4-wide tree, whose depth the builder
                                        // keeps at or below BVH_STACK / 3 (BvhBuilder::build)
 #ifndef PT_BVH_LDS_ENTRIES
-#define PT_BVH_LDS_ENTRIES 8
+#define PT_BVH_LDS_ENTRIES 10
 #endif
-constexpr int BVH_LDS_ENTRIES = PT_BVH_LDS_ENTRIES;    // of which this many live in LDS, the rest (rarely reached) in a global spill area
+constexpr int BVH_LDS_ENTRIES = PT_BVH_LDS_ENTRIES;    // of which this many live in LDS, the rest (rarely reached) in a global spill area;
+                                                       // 20 KiB per block: seven blocks per CU fit (measured on the 1M-rectangle
+                                                       // field: 8 entries 7 580, 9: 7 610, 10: 7 650, 11: 7 685, 12 - six blocks - 7 370 Mrays/s)
 constexpr int BVH_STACK_STRIDE = 256;  // threads per block of every kernel that traverses
 constexpr int BVH_MAX_LEAF = 1;        // primitives per leaf; measured on the 1M-rectangle field with 128-byte nodes:
                                        // 1 -> 3750, 2 -> 3650, 3 -> 3560, 4 -> 3440, 8 -> 3140 Mrays/s
@@ -238,10 +240,10 @@ __device__ __forceinline__ uint32_t bvh_step(const DevScene &sc, Trav &s, const 
         const float INF = __builtin_inff();
         // key = entry distance of a child the ray must visit, +inf otherwise (a child that does not exist is never entered:
         // its box is inside out)
-        float k0 = (tn0 <= tf0 && tn0 <= s.best_t) ? tn0 : INF;
-        float k1 = (tn1 <= tf1 && tn1 <= s.best_t) ? tn1 : INF;
-        float k2 = (tn2 <= tf2 && tn2 <= s.best_t) ? tn2 : INF;
-        float k3 = (tn3 <= tf3 && tn3 <= s.best_t) ? tn3 : INF;
+        float k0 = tn0 <= fminf(tf0, s.best_t) ? tn0 : INF;
+        float k1 = tn1 <= fminf(tf1, s.best_t) ? tn1 : INF;
+        float k2 = tn2 <= fminf(tf2, s.best_t) ? tn2 : INF;
+        float k3 = tn3 <= fminf(tf3, s.best_t) ? tn3 : INF;
         // (a child entered at distance +inf cannot hold a finite hit, so treating it as missed loses nothing)
         int j = 0;
         float kj = k0;
