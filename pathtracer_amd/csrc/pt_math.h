@@ -29,7 +29,29 @@ PT_HD V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 PT_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
 PT_HD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PT_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-PT_HD float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded square root.  On the device the compiler's expansion of it is 16 instructions, five of which scale
+// arguments below 2^-96 up and the result back down (the correction step's residual x - s'*s would lose bits there) and two
+// pass zeros and infinities through.  A wave none of whose lanes holds such an argument takes the same expansion without
+// those seven: hardware estimate s (1 ulp), then s - 1ulp when x - (s - 1ulp)*s <= 0, s + 1ulp when x - (s + 1ulp)*s > 0, both
+// residuals by fused multiply-add from the estimate - the same operations on the same operands, hence the same bits; zeros,
+// infinities, NaNs and negative arguments come out of the estimate right and fall through both corrections (every
+// comparison with their NaN residuals is false; sqrt(+-0): the neighbours' residuals are 0 and NaN).
+PT_HD float sqrt_ieee(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_FAST_SQRT)
+    // (one comparison: it also sends waves with a zero or a negative argument the long way, which costs less than a second
+    // instruction at every square root: measured on the sample scene +1.3 % against +0.9 %)
+    if (__builtin_amdgcn_ballot_w64(x < 0x1p-96f) == 0ull) {
+        const float est = __builtin_amdgcn_sqrtf(x);
+        const float below = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, est) - 1u);
+        const float above = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, est) + 1u);
+        const float r_below = __builtin_fmaf(-below, est, x), r_above = __builtin_fmaf(-above, est, x);
+        float s = r_below <= 0.0f ? below : est;
+        s = r_above > 0.0f ? above : s;
+        return s;
+    }
+#endif
+    return __builtin_sqrtf(x);
+}
 PT_HD float length(V3 a) { return sqrt_ieee(dot(a, a)); }
 PT_HD V3 normalize(V3 a) { return a / length(a); }
 
