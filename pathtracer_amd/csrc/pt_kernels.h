@@ -169,10 +169,13 @@ typedef const f4_t __attribute__((address_space(4))) *const_f4_ptr;
 // `transition`: the winner's Transition (0 In, 1 Out: a sphere left from inside).  BVH is a compile-time choice:
 // kernels for scenes without one carry no traversal code - with it inlined the fused kernel needs 117 instead of 89-95
 // registers (4 instead of 5 waves per SIMD: measured 20.4 vs 22.1 Grays/s on the sample scene).
+typedef const float4 __attribute__((address_space(3))) *lds_f4_ptr;
 template <bool BVH, bool DEFER = false>
-__device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t, int &transition) {
+__device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t, int &transition, lds_f4_ptr lds_sph = nullptr) {
     if (BVH) return bvh_nearest(sc, o, d, t, transition);
-    return nearest_brute<DEFER>((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
+    if (DEFER)   // (a lane's own candidate spheres come from the block's LDS copy of the scene)
+        return nearest_brute<true>((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition, lds_sph);
+    return nearest_brute<false>((const_f4_ptr)(uintptr_t)sc.sph, sc.n_sph, (const_f4_ptr)(uintptr_t)sc.pln, sc.n_pl, o, d, t, transition);
 }
 template <bool BVH>
 __device__ __forceinline__ uint32_t nearest_hit(const DevScene &sc, V3 o, V3 d, float &t) {
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(BLOCK, (BVH && FUSED) ? 4 : PT_SHADE_WAVES) void k_
             // primary rays of a linear-scan scene: a wave none of whose rays can reach the scene's box skips the scan
             const bool reach = !(RAYGEN && !BVH) || !sc.has_bounds || may_reach_box(sc.bounds_lo, sc.bounds_hi, o, d);
             if (FUSED) {
-                if (!(RAYGEN && !BVH) || __ballot(reach) != 0ull) prim = nearest_hit<BVH, DEFER>(sc, o, d, hit_t, hit_tr);
+                if (!(RAYGEN && !BVH) || __ballot(reach) != 0ull) prim = nearest_hit<BVH, DEFER>(sc, o, d, hit_t, hit_tr, (lds_f4_ptr)s_scene);
             } else {  // the trace kernel left the winner, its Transition and its distance
                 uint32_t word = L.hitprim()[i];
                 hit_t = L.hit_t()[i];

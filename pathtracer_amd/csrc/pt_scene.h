@@ -222,8 +222,10 @@ inline uint32_t plane_axis_code(V3 n, V3 s, V3 un, float ul, V3 vn, float vl, bo
 // scalar loads into SGPRs).
 // DEFER (device only, a kernel-level choice for scenes with more than DEFER_SPHERES spheres): see below.
 constexpr uint32_t DEFER_SPHERES = 8;
-template <bool DEFER = false, class P4>
-PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p, V3 d, float &best_t, int &best_out) {
+// `own_sph`: where a lane reads ITS candidate sphere from (the same table; the kernels pass their LDS copy, P4 itself is
+// a scalar-load pointer that suits fetches every lane shares).
+template <bool DEFER = false, class P4, class Q4 = P4>
+PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p, V3 d, float &best_t, int &best_out, Q4 own_sph = Q4()) {
     uint32_t best = MISS;
     best_t = 0.0f;
     best_out = 0;  // Transition of the winner (planes are only ever accepted as In)
@@ -232,9 +234,10 @@ PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p
     // sphere) is then tested in full lane by lane, each lane on ITS next candidate: the square roots run once or twice per
     // wave instead of once per sphere that any lane might hit.  A lane takes its candidates in ascending order and
     // replaces only when strictly closer, as the scan over all spheres does.  Measured at 1080p: the room with 20
-    // spheres +4 %, the sample scene with 3 spheres -3 % (the bookkeeping and the per-lane fetch cost more than two
-    // skipped rounds of roots save), hence the threshold - and a template parameter, because the mere presence of this
-    // loop in the sample scene's kernel costs it 0.5 %.
+    // spheres +9 % (candidates read from the block's LDS copy of the scene; +4 % when read from global memory), the
+    // sample scene with 3 spheres -1.3 % (the bookkeeping costs more than two skipped rounds of roots save), hence the
+    // threshold - and a template parameter, because the mere presence of this loop in the sample scene's kernel costs
+    // it 0.5 %.
     const bool deferred = DEFER;
     for (uint32_t first = 0; deferred && first < n_sph; first += 32u) {
         const uint32_t n = n_sph - first < 32u ? n_sph - first : 32u;
@@ -246,7 +249,7 @@ PT_HD uint32_t nearest_brute(P4 sph, uint32_t n_sph, P4 pln, uint32_t n_pl, V3 p
                 cand &= cand - 1u;
                 float t;
                 int out;
-                if (sphere_test(sph[i], p, d, t, out)) {
+                if (sphere_test(own_sph[i], p, d, t, out)) {
                     if (best == MISS || t < best_t) { best = i; best_t = t; best_out = out; }
                 }
             }
