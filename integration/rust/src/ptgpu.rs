@@ -194,6 +194,7 @@ extern "C" {
     pub fn ptgpu_stream(h: *mut PtHandle, stream: *mut *mut c_void) -> i32;
     pub fn ptgpu_get_stats(h: *mut PtHandle, out: *mut PtStats) -> i32;
     pub fn ptgpu_bvh_build_stats(scene: *const PtSceneDesc, out: *mut PtStats) -> i32;
+    pub fn ptgpu_bvh_host_trace(scene: *const PtSceneDesc, n_rays: u64, rays: *const f32, prims: *mut u32, ts: *mut f32, faults: *mut u64) -> i32;
     pub fn ptgpu_last_error(h: *mut PtHandle) -> *const c_char;
 
     pub fn ptgpu_group_create(cfg: *const PtConfig, devices: *const i32, n_devices: u32, out: *mut *mut PtGroup) -> i32;

@@ -250,6 +250,22 @@ static int intersect_plane(const pr_plane *plane, const pr_plane_axes *ax, pr_ve
     return 1;
 }
 
+/* Test hook: while a log is set, every find_scene_hit call appends its ray and its answer (8 words: origin.xyz,
+ * direction.xyz, bits of the primitive id, t) - the exact rays a render traces, for tests that replay them elsewhere.
+ * Rows beyond the capacity are counted but not stored.  Calls from the pool's threads interleave in any order. */
+static float *g_ray_log = NULL;
+static uint64_t g_ray_log_cap = 0, g_ray_log_n = 0;
+void ptref_ray_log(float *rows, uint64_t capacity) { g_ray_log = rows; g_ray_log_cap = rows ? capacity : 0; g_ray_log_n = 0; }
+uint64_t ptref_ray_log_count(void) { return g_ray_log_n; }
+static void log_ray(pr_vec3 p, pr_vec3 d, uint32_t prim_id, float t) {
+    uint64_t k = __atomic_fetch_add(&g_ray_log_n, 1, __ATOMIC_RELAXED);
+    if (k >= g_ray_log_cap) return;
+    float *r = g_ray_log + 8 * k;
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+    memcpy(&r[6], &prim_id, 4);
+    r[7] = t;
+}
+
 /* scene.rs:263-297.  Iteration (and id) order: spheres, emissive_spheres, planes, emissive_planes;
  * a later hit replaces the nearest only when strictly closer; planes count only with Transition::In. */
 static int find_scene_hit(const pr_scene *scene, const pr_plane_axes *axes, pr_vec3 p, pr_vec3 d, pr_hit *out,
@@ -284,6 +300,7 @@ static int find_scene_hit(const pr_scene *scene, const pr_plane_axes *axes, pr_v
     }
     if (found) *out = best;
     else out->prim_id = 0xFFFFFFFFu;
+    if (g_ray_log) log_ray(p, d, out->prim_id, found ? best.t : 0.0f);
     return found;
 }
 

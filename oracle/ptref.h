@@ -158,6 +158,11 @@ void ptref_render_pass_pool(const pr_scene *scene, const pr_options *opt, pr_bac
 /* Primary-hit primitive ids for one sample index (row-major y*width+x), 0xFFFFFFFF = miss. */
 void ptref_primary_ids(const pr_scene *scene, const pr_options *opt, uint32_t sample_index, uint32_t *ids);
 
+/* Test hook: log every find_scene_hit call made from now on into rows[capacity][8] (origin.xyz, direction.xyz, bits of
+ * the primitive id found - 0xFFFFFFFF none -, t); NULL stops.  ptref_ray_log_count: calls since the log was set. */
+void ptref_ray_log(float *rows, uint64_t capacity);
+uint64_t ptref_ray_log_count(void);
+
 /* pixels8 from pixels32 (tracer.rs:271-282) for every pixel with the given num_samples. */
 void ptref_assign_pixels8(const pr_scene *scene, const uint32_t *pixels32, uint64_t num_samples, uint8_t *pixels8);
 

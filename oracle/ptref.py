@@ -200,6 +200,24 @@ class OracleScene:
         lib().ptref_primary_ids(C.byref(self.desc), C.byref(opt), sample_index, out.ctypes.data)
         return out
 
+    def render_logging_rays(self, opt: Options, n_samples: int, capacity: int = 1 << 22):
+        """render() on one thread with the ray log on: (pixels32, pixels8, rays, log) where log[k] = (origin.xyz,
+        direction.xyz, bits of the primitive id found, t) of the k-th find_scene_hit call."""
+        L = lib()
+        L.ptref_ray_log.argtypes = [C.c_void_p, C.c_uint64]
+        L.ptref_ray_log.restype = None
+        L.ptref_ray_log_count.restype = C.c_uint64
+        log = np.zeros((capacity, 8), dtype=np.float32)
+        L.ptref_ray_log(log.ctypes.data, capacity)
+        try:
+            p32, p8, rays = self.render(opt, n_samples)
+            n = int(L.ptref_ray_log_count())
+        finally:
+            L.ptref_ray_log(None, 0)
+        if n > capacity:
+            raise ValueError(f"ray log too small: {n} calls")
+        return p32, p8, rays, log[:n]
+
     # -- accumulation ----------------------------------------------------------------------------------
     def render(self, opt: Options, n_samples: int, sample_indices=None, threads: int = 0):
         """n_samples passes over the image.  Returns (pixels32, pixels8, rays).  sample_indices defaults to

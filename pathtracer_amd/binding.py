@@ -128,6 +128,8 @@ def load_library() -> C.CDLL:
         getattr(lib, "ptgpu_group_" + name).restype = C.c_int
     lib.ptgpu_bvh_build_stats.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtStats)]
     lib.ptgpu_bvh_build_stats.restype = C.c_int
+    lib.ptgpu_bvh_host_trace.argtypes = [C.POINTER(PtSceneDesc), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.ptgpu_bvh_host_trace.restype = C.c_int
     lib.ptgpu_last_error.argtypes = [H]
     lib.ptgpu_last_error.restype = C.c_char_p
     lib.ptgpu_camera_new.argtypes = [PtVec3, PtVec3, PtVec3, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float,
@@ -208,6 +210,22 @@ def bvh_build_stats(scene: S.Scene) -> dict:
         raise PtGpuError(rc, "ptgpu_bvh_build_stats failed")
     return {k: int(getattr(st, k)) for k in ("bvh_nodes", "bvh_leaf_prims", "bvh_depth", "bvh_binary_depth",
                                              "bvh_forced_median_splits", "bvh_level_fold")}
+
+
+def bvh_host_trace(scene: S.Scene, rays: np.ndarray):
+    """Nearest primitive and distance for each ray (rows of origin.xyz, direction.xyz), found by the kernels' traversal
+    functions compiled for the CPU (host only: works without a GPU), and the checker's counts: (prims, ts, faults) with
+    faults = dict(bad_units, bad_kinds, bad_slots, steps)."""
+    sd = SceneDesc(scene)
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    prims = np.empty(n, dtype=np.uint32)
+    ts = np.empty(n, dtype=np.float32)
+    faults = (C.c_uint64 * 4)()
+    rc = load_library().ptgpu_bvh_host_trace(C.byref(sd.desc), n, rays.ctypes.data, prims.ctypes.data, ts.ctypes.data, faults)
+    if rc != 0:
+        raise PtGpuError(rc, "ptgpu_bvh_host_trace failed")
+    return prims, ts, dict(bad_units=int(faults[0]), bad_kinds=int(faults[1]), bad_slots=int(faults[2]), steps=int(faults[3]))
 
 
 def _stats_dict(st: PtStats) -> dict:

@@ -60,6 +60,14 @@ struct BvhBuilder {
     std::vector<uint32_t> idx;
     std::vector<BuildNode> bn;
     double pad = 0.0;
+    double scene_size = 0.0;   // M: the largest |coordinate| of the camera and of every box in the tree; pad = M * 2^-16
+
+    // Ray origins within this of the centre (the sum of their |coordinates|) are "tame" for the traversal (bvh_begin): every
+    // cell of every node is at least 2 * pad / 255 = M * 2^-23 wide (write_node), a tame origin is at most 17 M from a
+    // node's corner, so entry and exit of an inside-out box differ by 255 cells >= 2^-15 M against a slab distance of at
+    // most 17 M: 1.8e-6 of it, where the widening of the exit (5e-7) and three roundings (6e-8 each) take 0.7e-6.
+    // (Beyond 2^62 the slab products may overflow; such origins are not tame whatever the scene's size.)
+    float tame_reach() const { return (float)std::min(std::ldexp(scene_size, BVH_TAME_REACH_LOG2), std::ldexp(1.0, 62)); }
     const std::vector<float4> *src_sph = nullptr, *src_pln = nullptr;
 
     static bool finite3(double a, double b, double c) { return std::isfinite(a) && std::isfinite(b) && std::isfinite(c); }
@@ -217,6 +225,7 @@ struct BvhBuilder {
             }
         }
         pad = std::ldexp(std::max(M, 1e-30), -16);
+        scene_size = std::max(M, 1e-30);
         std::sort(always.begin(), always.end());
     }
 
@@ -334,13 +343,14 @@ struct BvhBuilder {
         int ex[3] = {0, 0, 0};
         uint8_t qlo[4][3], qhi[4][3];
         for (int j = 0; j < 4; ++j) for (int d = 0; d < 3; ++d) { qlo[j][d] = 255; qhi[j][d] = 0; }   // no such child: inside out
-        for (int d = 0; d < 3 && n > 0; ++d) {
-            double lo_min = lo[0][d], hi_max = hi[0][d];
+        for (int d = 0; d < 3; ++d) {
+            // (a node without children - the root of a scene with nothing to bound - keeps the cell size every node has at least)
+            double lo_min = n > 0 ? lo[0][d] : 0.0, hi_max = n > 0 ? hi[0][d] : 0.0;
             for (int j = 1; j < n; ++j) { lo_min = std::min<double>(lo_min, lo[j][d]); hi_max = std::max<double>(hi_max, hi[j][d]); }
             org[d] = (float)lo_min;
-            const double ext = hi_max - lo_min;
-            int e = -100;
-            if (ext > 0.0) { e = std::max(-100, std::ilogb(ext / 255.0)); while (255.0 * std::ldexp(1.0, e) < ext) ++e; }
+            const double ext = std::max(hi_max - lo_min, 2.0 * pad);   // (2 * pad at least anyway: every box is padded on both sides)
+            int e = std::max(-100, std::ilogb(ext / 255.0));
+            while (255.0 * std::ldexp(1.0, e) < ext) ++e;
             ex[d] = e;   // (at most BVH_MAX_EXPONENT - 7: boxes() keeps the extent below 2^BVH_MAX_EXPONENT)
             const double cell = std::ldexp(1.0, e);
             for (int j = 0; j < n; ++j) {

@@ -226,6 +226,15 @@ __device__ __forceinline__ uint32_t pack_hit(uint32_t prim, int transition) {
     return prim == MISS ? MISS : (prim | (transition == 1 ? HIT_OUT_BIT : 0u));
 }
 
+// What a kernel that traverses the tree leaves in hitprim for a ray whose answer only the reference's own scan over every
+// primitive can give (BVH_RESCAN in pt_bvh.h: a NaN distance was accepted, or the ray is not finite).  The count of such
+// records of a level is kept in word 2 of the level's first counter line (zeroed with the counters, every pass), and a
+// second kernel, launched behind the first, repeats them with the linear scan - or returns at once when the count is
+// zero, which is what it is unless a scene holds NaN or infinite coordinates or a sphere of radius zero.  Keeping the
+// scan out of the traversing kernels keeps its registers out of them (inlined it cost k_trace_dyn 36 spilled registers
+// and the terminal kernel two of its six waves per SIMD).
+constexpr uint32_t HIT_RESCAN = 0xFFFFFFFEu;
+
 // ---- trace: reference src/scene.rs:263-297 ------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, Level L) {
     if (pass_voided(L)) return;
@@ -290,6 +299,15 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
     bool exhausted = false, active = false;
     Trav st;
     st.node = BVH_EMPTY;
+    auto finish_record = [&]() {
+        uint32_t code = pack_hit(st.best == MISS ? MISS : st.best_slot, st.best_out & 1);   // by shading row, not by id
+        if (st.best_out & BVH_RESCAN) {   // (degenerate data only: k_rescan, which follows this kernel, decides)
+            code = HIT_RESCAN;
+            atomicAdd(L.count + 2, 1u);
+        }
+        L.hitprim()[rec] = code;
+        L.hit_t()[rec] = st.best_t;
+    };
     uint32_t my_steps = 0;  // 64-byte units (2 per inner node, 1 per leaf primitive) this lane fetched: the kernel's algorithmic traffic
     for (;;) {
         unsigned long long idle = __ballot(!active);
@@ -332,7 +350,8 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
                     ro = v3(a.x, a.y, a.z); rd = v3(a.w, b.x, b.y);
                 }
                 bvh_begin(sc, ro, rd, st);
-                active = true;
+                active = st.node != BVH_EMPTY;
+                if (!active) finish_record();   // (a ray that is not let into the tree: left to k_rescan)
 #ifdef PT_TRAV_STATS
                 if (ray_steps > max_steps) max_steps = ray_steps;
                 ray_steps = 0;
@@ -353,8 +372,7 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #endif
                 my_steps += bvh_step(sc, st, stk, (it & (DYN_LEAF_EVERY - 1)) == DYN_LEAF_EVERY - 1);
                 if (st.node == BVH_EMPTY) {
-                    L.hitprim()[rec] = pack_hit(st.best == MISS ? MISS : st.best_slot, st.best_out);   // by shading row, not by id
-                    L.hit_t()[rec] = st.best_t;
+                    finish_record();
                     active = false;
                 }
             }
@@ -369,6 +387,31 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #ifdef PT_TRAV_STATS
     atomicAdd(&ctr->stamps[0], n_steps); atomicAdd(&ctr->stamps[1], n_slots); atomicAdd(&ctr->stamps[2], n_leaf); atomicMax(&ctr->stamps[3], max_steps > ray_steps ? max_steps : ray_steps);
 #endif
+}
+
+// The records k_trace_dyn left to the linear scan (HIT_RESCAN); same template parameter.
+template <bool RAYGEN>
+__global__ __launch_bounds__(BLOCK) void k_rescan(DevScene sc, Level L, PassParams pp) {
+    if (pass_voided(L) || L.count[2] == 0u) return;
+    TileMap m = tile_map(L);
+    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
+        uint32_t i;
+        if (!tile_record(m, L, w, i)) continue;
+        if (L.hitprim()[i] != HIT_RESCAN) continue;
+        V3 o, d;
+        if (RAYGEN) {
+            uint32_t skey;
+            primary_ray(sc, pp, i, o, d, skey);
+        } else {
+            float4 a = L.rayA()[i], b = L.rayB()[i];
+            o = v3(a.x, a.y, a.z); d = v3(a.w, b.x, b.y);
+        }
+        float t;
+        int tr;
+        const uint32_t prim = nearest_brute<false>(sc.sph, sc.n_sph, sc.pln, sc.n_pl, o, d, t, tr);
+        L.hitprim()[i] = pack_hit(prim == MISS ? MISS : sc.prim_rows[prim], tr);
+        L.hit_t()[i] = t;
+    }
 }
 
 // The backward sweep works on PAIRS of levels.  A node of an even level PULLS the radiance of its children out of
@@ -837,15 +880,22 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene
 // ---- terminal level (depth == 0): reference src/tracer.rs:451-492 ------------------------------------------------
 // Holds only the light samples that need a shadow ray (k_shade drops the others).  `shadow_count` is a row of
 // per-shard counters like Level::count (zeroed every pass, summed by k_account).
-template <bool BVH>
-__global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level Lprev, uint32_t *shadow_count) {
+// RESCAN: the second kernel of a BVH scene (see HIT_RESCAN) - only the records the first one marked, by linear scan.
+// (Six waves per SIMD for the traversing kernel: two registers over that budget would cost it the sixth.)
+template <bool BVH, bool RESCAN = false>
+__global__ __launch_bounds__(BLOCK, BVH ? 6 : 1) void k_terminal(DevScene sc, Level L, Level Lprev, uint32_t *shadow_count) {
     if (pass_voided(L)) return;
+    if (RESCAN && L.count[2] == 0u) return;
     TileMap m = tile_map(L);
     uint32_t n_shadow = 0;
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         bool valid = tile_record(m, L, w, i);
         bool shadow = false;
+        if (RESCAN && valid) {   // (the level's hitprim array has no other use: terminal records are not traced)
+            valid = L.hitprim()[i] == HIT_RESCAN;
+            if (valid) L.hitprim()[i] = 0u;
+        }
         if (valid) {
             float4 a = L.rayA()[i], b = L.rayB()[i];
             V3 o = v3(a.x, a.y, a.z);
@@ -855,7 +905,12 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
             shadow = terminal_sample(sc, o, nkey, dir, dist, radiance);
             if (shadow) {
                 if (BVH) {
-                    if (bvh_light_visible(sc, o, dir, dist)) value = radiance;   // stops at the first occluder
+                    const int lit = bvh_light_visible(sc, o, dir, dist);   // stops at the first occluder
+                    if (lit == 1) value = radiance;
+                    if (lit == LIGHT_RESCAN) {   // (degenerate data only: the RESCAN launch that follows decides)
+                        L.hitprim()[i] = HIT_RESCAN;
+                        atomicAdd(L.count + 2, 1u);
+                    }
                 } else {
                     float t;
                     uint32_t prim = nearest_hit<false>(sc, o, dir, t);
@@ -868,7 +923,7 @@ __global__ __launch_bounds__(BLOCK) void k_terminal(DevScene sc, Level L, Level 
         }
         n_shadow += (uint32_t)__popcll(__ballot(shadow));
     }
-    if (n_shadow != 0 && lane_id() == 0) atomicAdd(&shadow_count[my_shard() * CSTRIDE], n_shadow);
+    if (!RESCAN && n_shadow != 0 && lane_id() == 0) atomicAdd(&shadow_count[my_shard() * CSTRIDE], n_shadow);
 }
 
 // ---- backward sweep: the inner nodes of an even level l >= 2 hand their radiance to their parents -----------------

@@ -43,6 +43,8 @@ struct DevScene {
                                 //   (kind, color.xyz) (roughness, metalness, ior, bits(primitive id)) (f0.xyz, 0) (plane normal or sphere
                                 //   centre .xyz, 0); the BVH trace kernel reports hits by this row
     uint32_t n_bvh_units;       // units of the tree (the rows of the `always` primitives follow)
+    const uint32_t *prim_rows;  // [n_sph + n_pl] the shading row of every primitive (the inverse of the rows' order)
+    float bvh_reach;            // ray origins with every |coordinate| at or below this are "tame" (pt_bvh.h, bvh_begin)
     // camera (reference src/tracer.rs:104-111: per-pixel step vectors of CameraSampler)
     V3 cam_origin, cam_su, cam_sv, cam_pos;
     int tone; float exposure; float iso_factor;

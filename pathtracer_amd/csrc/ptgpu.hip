@@ -63,7 +63,7 @@ struct PtHandle {
     float4 *d_sph = nullptr, *d_pln = nullptr, *d_mat = nullptr, *d_lights = nullptr;
     float *d_sky = nullptr, *d_gamma = nullptr;
     float4 *d_bvh_nodes = nullptr, *d_shade_rows = nullptr;
-    uint32_t *d_bvh_always = nullptr;
+    uint32_t *d_bvh_always = nullptr, *d_prim_rows = nullptr;
     uint64_t bvh_nodes = 0, bvh_leaf_prims = 0;
     uint64_t bvh_depth = 0, bvh_binary_depth = 0, bvh_forced_median_splits = 0, bvh_level_fold = 0;
     bool has_glass = false;
@@ -182,7 +182,7 @@ void free_levels(PtHandle *h) {
 
 void free_scene(PtHandle *h) {
     dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
-    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_always); dev_free(h->d_shade_rows);
+    dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_always); dev_free(h->d_prim_rows); dev_free(h->d_shade_rows);
     dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
     if (h->h_pixels8) { (void)hipHostFree(h->h_pixels8); h->h_pixels8 = nullptr; }
     free_levels(h);
@@ -267,6 +267,24 @@ void flatten_scene(const PtSceneDesc *s, std::vector<float4> &sph, std::vector<f
     }
 }
 
+// What the traversal needs to know of the builder's padding.
+void apply_builder_limits(DevScene &sc, const BvhBuilder &b) { sc.bvh_reach = b.tame_reach(); }
+
+// Shading rows are ordered as the trace kernel names hits: by unit of the tree (a leaf primitive's; the rows of node units
+// stay empty), then the `always` list.  The inverse, for the scan over all primitives (bvh_finish): primitive -> row
+// (MISS for a plane with a NaN normal, which is in neither and which no ray hits).
+std::vector<uint32_t> shading_order(const BvhBuilder &b) {
+    std::vector<uint32_t> order(b.unit_prim);
+    order.insert(order.end(), b.always.begin(), b.always.end());
+    return order;
+}
+std::vector<uint32_t> rows_of_primitives(const std::vector<uint32_t> &order, size_t n_prims) {
+    std::vector<uint32_t> rows(std::max<size_t>(1, n_prims), MISS);
+    for (size_t k = 0; k < order.size(); ++k)
+        if (order[k] != BvhBuilder::MISS_ID) rows[order[k]] = (uint32_t)k;
+    return rows;
+}
+
 hipEvent_t get_event(PtHandle *h) {
     if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -305,7 +323,7 @@ __global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t sha
     uint32_t c = 0;
     if (start < n_records) c = (uint32_t)std::min<uint64_t>(shard_cap, n_records - start);
     count0[q * CSTRIDE] = c;
-    if (q == 0) count0[1] = 0;  // work counter of the dynamic-fetch trace kernel
+    if (q == 0) { count0[1] = 0; count0[2] = 0; }  // work counter of the dynamic-fetch trace kernel; its count of records left to k_rescan
 }
 
 uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
@@ -431,6 +449,7 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     const size_t lds = h->lds_bytes;
     // kernels that walk the BVH index a per-thread spill area sized for BVH_TRAV_BLOCKS blocks
     const bool bvh = sc.bvh_nodes != nullptr;
+    const uint32_t RESCAN_GRID = 512;   // (of the kernels that repeat the few records a traversing kernel left to the linear scan)
     const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
     HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
@@ -483,8 +502,9 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
         } else {
             {
                 Span s(h, PT_KERNEL_TRACE, st);
-                if (bvh && l == 0) k_trace_dyn<true><<<TG, BLOCK, lds, st>>>(sc, L, pp, h->d_ctr);
-                else if (bvh) k_trace_dyn<false><<<TG, BLOCK, lds, st>>>(sc, L, pp, h->d_ctr);
+                // (k_rescan: returns at once unless the trace kernel met rays only the linear scan can answer)
+                if (bvh && l == 0) { k_trace_dyn<true><<<TG, BLOCK, lds, st>>>(sc, L, pp, h->d_ctr); k_rescan<true><<<RESCAN_GRID, BLOCK, 0, st>>>(sc, L, pp); }
+                else if (bvh) { k_trace_dyn<false><<<TG, BLOCK, lds, st>>>(sc, L, pp, h->d_ctr); k_rescan<false><<<RESCAN_GRID, BLOCK, 0, st>>>(sc, L, pp); }
                 else k_trace<<<TG, BLOCK, lds, st>>>(sc, L);
             }
             Span s(h, PT_KERNEL_SHADE, st);
@@ -497,8 +517,10 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     {
         Span s(h, PT_KERNEL_TERMINAL, st);
         uint32_t *shadow_row = pipe.d_counts + (size_t)h->n_levels * NSHARD * CSTRIDE;
-        if (bvh) k_terminal<true><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
-        else k_terminal<false><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
+        if (bvh) {
+            k_terminal<true><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
+            k_terminal<false, true><<<RESCAN_GRID, BLOCK, 0, st>>>(sc, levels[D], levels[D - 1], shadow_row);
+        } else k_terminal<false><<<TG, BLOCK, lds, st>>>(sc, levels[D], levels[D - 1], shadow_row);
     }
     // Backward sweep over the even levels, deepest first; each pulls from the odd level above it (when that is a
     // traced level) and pushes into the odd level below.  With max_depth 1 level 1 holds terminal samples, which push.
@@ -815,10 +837,13 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
             HIPCHK(h, hipMemcpy(h->d_bvh_always, builder.always.data(), builder.always.size() * 4, hipMemcpyHostToDevice));
         sc.bvh_nodes = h->d_bvh_nodes;  // (the spill area belongs to the pipes)
         sc.bvh_always = h->d_bvh_always; sc.n_always = (uint32_t)builder.always.size();
-        {   // shading rows, in the order the trace kernel names hits: by unit of the tree (a leaf primitive's; the rows of node
-            // units stay empty), then the `always` list
-            std::vector<uint32_t> order(builder.unit_prim);
-            order.insert(order.end(), builder.always.begin(), builder.always.end());
+        apply_builder_limits(sc, builder);
+        {
+            const std::vector<uint32_t> order = shading_order(builder);
+            const std::vector<uint32_t> prim_rows = rows_of_primitives(order, n_sph + n_pl);
+            if ((rc = dev_alloc(h, &h->d_prim_rows, prim_rows.size()))) return rc;
+            HIPCHK(h, hipMemcpy(h->d_prim_rows, prim_rows.data(), prim_rows.size() * 4, hipMemcpyHostToDevice));
+            sc.prim_rows = h->d_prim_rows;
             std::vector<float4> rows(4 * std::max<size_t>(1, order.size()), make_float4(0.f, 0.f, 0.f, 0.f));
             for (size_t k = 0; k < order.size(); ++k) {
                 const uint32_t id = order[k];
@@ -1218,6 +1243,60 @@ int ptgpu_bvh_build_stats(const PtSceneDesc *s, PtStats *out) {
     out->bvh_level_fold = builder.level_fold ? 1 : 0;
     // every primitive inside the (quantised) box of every node above it, each reachable exactly once
     return builder.check() == 0 ? PT_OK : PT_ERR_INTERNAL;
+    PT_API_END(nullptr)
+}
+
+// The traversal functions of the kernels, compiled for the host, over caller-supplied rays: builds the tree for `s` and
+// walks it on the CPU, one ray after the other, with every unit reference and stack slot checked.
+int ptgpu_bvh_host_trace(const PtSceneDesc *s, uint64_t n_rays, const float *rays, uint32_t *prims, float *ts, uint64_t *faults) {
+    PT_API_BEGIN
+    if (!s || (n_rays && (!rays || !prims || !ts)) || !faults) return PT_ERR_INVALID_ARGUMENT;
+    if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_emissive_spheres && !s->emissive_spheres) ||
+        (s->n_emissive_planes && !s->emissive_planes))
+        return PT_ERR_INVALID_ARGUMENT;
+    if (s->n_spheres + s->n_emissive_spheres + s->n_planes + s->n_emissive_planes >= (1ull << 28)) return PT_ERR_INVALID_ARGUMENT;
+    std::vector<float4> sph, pln, mat, lights;
+    bool glass = false;
+    flatten_scene(s, sph, pln, mat, lights, glass);
+    BvhBuilder builder;
+    builder.build(sph, pln, toV3(s->camera.position), toV3(s->camera.plane_origin));
+    DevScene sc{};
+    sc.n_sph = (uint32_t)sph.size(); sc.n_pl = (uint32_t)(pln.size() / 4);
+    sc.sph = sph.data(); sc.pln = pln.data();
+    sc.bvh_nodes = builder.units.data();
+    sc.n_bvh_units = (uint32_t)builder.unit_prim.size();
+    sc.bvh_always = builder.always.data(); sc.n_always = (uint32_t)builder.always.size();
+    apply_builder_limits(sc, builder);
+    const std::vector<uint32_t> prim_rows = rows_of_primitives(shading_order(builder), sph.size() + pln.size() / 4);
+    sc.prim_rows = prim_rows.data();
+    // one lane's stack, laid out and strided exactly as a lane of the kernels sees it
+    std::vector<unsigned long long> lds((size_t)BVH_LDS_ENTRIES * BVH_STACK_STRIDE);
+    unsigned long long *spill = (unsigned long long *)std::calloc((size_t)(BVH_STACK - BVH_LDS_ENTRIES) * BVH_TRAV_BLOCKS * BVH_STACK_STRIDE, 8);
+    if (!spill) return PT_ERR_INTERNAL;
+    TravStack stk;
+    stk.lds = (lds_u64 *)(uintptr_t)lds.data();
+    stk.spill = spill;
+    BvhHostCheck &chk = bvh_host_check();
+    chk = BvhHostCheck();
+    chk.unit_prim = builder.unit_prim.data();
+    uint64_t steps = 0;
+    for (uint64_t r = 0; r < n_rays; ++r) {
+        Trav st;
+        bvh_begin(sc, v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]), v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]), st);
+        // (leaf primitives wait for every second step, as in the trace kernel; a walk that does not end is a fault too)
+        uint64_t it = 0;
+        const uint64_t limit = 64ull * builder.unit_prim.size() + 64;
+        for (; st.node != BVH_EMPTY && it < limit; ++it) steps += bvh_step(sc, st, stk, (it & 1u) == 1u);
+        if (st.node != BVH_EMPTY) ++chk.bad_units;
+        bvh_finish(sc, st);
+        if (st.best != MISS && (st.best_slot >= prim_rows.size() + builder.unit_prim.size() || prim_rows[st.best] != st.best_slot)) ++chk.bad_kinds;   // (the hit's shading row)
+        prims[r] = st.best;
+        ts[r] = st.best_t;
+    }
+    std::free(spill);
+    faults[0] = chk.bad_units; faults[1] = chk.bad_kinds; faults[2] = chk.bad_slots; faults[3] = steps;
+    chk.unit_prim = nullptr;
+    return PT_OK;
     PT_API_END(nullptr)
 }
 

@@ -294,3 +294,34 @@ def test_random_clutter_bvh_equals_linear_scan_and_oracle(binding, oracle, seed)
     assert np.array_equal(ids, osc.primary_ids(oracle.options(max_depth=5), 1))
     r32, _, r_rays = osc.render(oracle.options(max_depth=5), 2)
     assert np.array_equal(p32, r32) and rays == r_rays
+
+
+def _degenerate_scenes():
+    from test_bvh_host_trace import _scenes, point_sphere_scene
+    yield "point sphere hit in its centre", point_sphere_scene(), 3, True
+    by_name = dict(_scenes())
+    yield "small scene over a long strip", by_name["small scene over a long strip"], 3, True
+    yield "unboundable only", by_name["unboundable only"], 2, True
+    for where in ("first", "last"):   # (every ray that faces it "hits" it at distance NaN)
+        yield f"a plane at NaN ({where})", by_name[f"a plane at NaN ({where})"], 3, False
+
+
+@pytest.mark.parametrize("name,sc,depth,pixels_vs_oracle", list(_degenerate_scenes()), ids=[n for n, *_ in _degenerate_scenes()])
+def test_degenerate_rays_and_primitives(binding, oracle, name, sc, depth, pixels_vs_oracle):
+    """Rays and primitives the tree cannot answer for - a NaN origin after a hit in the centre of a sphere of radius zero,
+    origins far outside the tree, distances that are NaN - are repeated by the linear scan in a second kernel; the image
+    must be the linear-scan pipeline's, bit for bit, and nothing may leave the tree on the way (that is a memory fault)."""
+    ids_b, p_b, st_b = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 3, max_depth=depth)
+    ids_l, p_l, st_l = _ids_and_pixels(binding, sc, binding.ACCEL_BRUTE_FORCE, 3, max_depth=depth)
+    for a, b in zip(ids_b, ids_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_b, p_l) and st_b["rays"] == st_l["rays"]
+    # the fused BVH kernels repeat such rays in place
+    _, p_f, st_f = _ids_and_pixels(binding, sc, binding.ACCEL_BVH, 3, max_depth=depth, fuse_trace_shade=1)
+    assert np.array_equal(p_f, p_l) and st_f["rays"] == st_l["rays"]
+    osc = oracle.OracleScene(sc)
+    opt = oracle.options(max_depth=depth)
+    assert np.array_equal(ids_b[1], osc.primary_ids(opt, 1))
+    if pixels_vs_oracle:   # (a NaN radiance becomes an integer differently on the two machines)
+        r32, _, rays = osc.render(opt, 3)
+        assert np.array_equal(p_b, r32) and st_b["rays"] == rays

@@ -98,6 +98,10 @@ def random_scene(seed, width=48, height=36):
     if rng.rand() < 0.25:
         tex = rng.uniform(0.0, 4.0, (8, 16, 3)).astype(np.float32)
         sc.sky = S.Sky.hdri("random.hdr", tex)
+    if rng.rand() < 0.25:  # a crowd of small spheres, some overlapping: more than eight spheres send the linear scan's full sphere
+        #                    tests through its per-lane candidate masks (more than 32: across the masks' chunk boundary)
+        for _ in range(int(rng.choice([6, 12, 30, 45]))):
+            sc.add(S.Sphere(tuple(float(x) for x in rng.uniform(-5.0, 5.0, 3) + np.array([0.0, 5.0, 0.0])), float(rng.uniform(0.1, 1.2)), _material(rng)))
     return sc, int(rng.randint(1, 7)), int(rng.randint(0, 2))
 
 
