@@ -220,7 +220,8 @@ int ptgpu_bvh_build_stats(const PtSceneDesc *scene, PtStats *out);
  * the CPU, one ray after the other: rays = n_rays x (origin.xyz, direction.xyz); prims[r] = id of the nearest primitive
  * (0xFFFFFFFF: none - find_scene_hit's None, src/scene.rs:263-297), ts[r] its distance.  Every reference to a unit of the
  * structure and every stack slot is checked on the way: faults[0] = references outside the structure or walks that did
- * not end, [1] = references to a unit of the other kind (node / primitive), [2] = stack slots outside the stack,
+ * not end, [1] = references to a unit of the other kind (node / primitive), distances that are NaN from a primitive
+ * inside the structure and hits whose shading row is wrong, [2] = stack slots outside the stack,
  * [3] = units fetched (faults points at four words).  A diagnostic for tests: it answers "which primitive" for any ray, including rays no scene
  * produces, without a GPU to fault. */
 int ptgpu_bvh_host_trace(const PtSceneDesc *scene, uint64_t n_rays, const float *rays, uint32_t *prims, float *ts, uint64_t *faults);

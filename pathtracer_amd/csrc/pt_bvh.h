@@ -93,10 +93,18 @@ PT_HD float slab_reciprocal(float d) {
 // accepted by the reference's plane test (its conditions are written so that a NaN passes: a plane whose origin is NaN,
 // a ray whose origin is) and then follows the scan's own rule - "replace only when strictly closer": the first hit in
 // id order stays for good when its distance is NaN, a later NaN never replaces anything.  No order-free rule gives
-// that, so an accepted NaN marks the ray (BVH_RESCAN in best_out) and bvh_finish repeats the scan itself.
+// that, so an accepted NaN marks the ray (BVH_RESCAN in best_out) and the scan itself is repeated for it (bvh_finish,
+// k_rescan).  Only the primitives OUTSIDE the tree can do that to a ray that is let into the tree (bvh_begin): inside
+// it every coordinate is finite and below 2^61, the ray's origin too, its direction of ordinary size, and then a
+// sphere's distance is a sum of two finite terms and a plane's a quotient of a finite numerator and a denominator of at
+// least 1e-7 - so the walk itself uses the plain rule (the host build counts a NaN there as a fault).
 constexpr int BVH_RESCAN = 2;
 PT_HD void bvh_accept(bool hit, float t, uint32_t id, int out, uint32_t slot, uint32_t &best, float &best_t, int &best_out,
                                            uint32_t &best_slot) {
+    if (hit && (t < best_t || (t == best_t && id < best))) { best = id; best_t = t; best_out = out; best_slot = slot; }
+}
+PT_HD void bvh_accept_outside(bool hit, float t, uint32_t id, int out, uint32_t slot, uint32_t &best, float &best_t, int &best_out,
+                                                   uint32_t &best_slot) {
     if (hit) {
         if (t < best_t || (t == best_t && id < best)) { best = id; best_t = t; best_out = out | (best_out & BVH_RESCAN); best_slot = slot; }
         else if (t != t) best_out |= BVH_RESCAN;
@@ -117,7 +125,7 @@ PT_HD void bvh_test_prims(const DevScene &sc, const uint32_t *ids, uint32_t n, V
             V3 pos;
             hit = plane_test(sc.pln[4 * p], sc.pln[4 * p + 1], sc.pln[4 * p + 2], sc.pln[4 * p + 3], o, d, t, pos);
         }
-        bvh_accept(hit, t, id, out, sc.n_bvh_units + k, best, best_t, best_out, best_slot);
+        bvh_accept_outside(hit, t, id, out, sc.n_bvh_units + k, best, best_t, best_out, best_slot);
     }
 }
 
@@ -237,6 +245,9 @@ PT_HD void bvh_test_record(const DevScene &sc, float4 a, float4 b, float4 c, flo
     int out = 0;
     if (id < sc.n_sph) hit = sphere_test(a, s.o, s.d, t, out);
     else { V3 pos; hit = plane_test(a, b, c, e, s.o, s.d, t, pos); }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (hit && t != t) ++bvh_host_check().bad_kinds;
+#endif
     bvh_accept(hit, t, id, out, slot, s.best, s.best_t, s.best_out, s.best_slot);
 }
 
