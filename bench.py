@@ -290,15 +290,15 @@ def main() -> None:
             children = st["records"] - st["samples"]         # records appended to levels >= 1
             if name == "trace_shade":
                 # per traced record: read ray 32 (not at level 0: primary rays are generated in the kernel),
-                # write kind 4 + coef-or-leaf-value 16; per appended child: write ray 32 + parent 4
-                # (the 4-byte child link written by the records of even levels is not priced)
-                alg = 52.0 * traced - 32.0 * st["samples"] + 36.0 * children
+                # write coef-or-leaf-value 16 (the node kind travels in its fourth word); per appended child: write
+                # ray 32 + parent 4 (the 4-byte child link written by the records of even levels is not priced)
+                alg = 48.0 * traced - 32.0 * st["samples"] + 36.0 * children
             elif name == "trace":
                 # read ray 32, write prim id 4; BVH: one 64-byte fetch per traversal step (inner node or leaf
                 # primitive), counted by the kernel itself (deterministic per ray, independent of scheduling)
                 alg = 36.0 * traced + 64.0 * st["bvh_steps"]
             elif name == "shade":
-                alg = 56.0 * traced + 36.0 * children
+                alg = 52.0 * traced + 36.0 * children   # read ray 32 + hit 4, write node 16
             else:
                 alg = 0.0
             ms = kms[name]

@@ -54,14 +54,13 @@ struct Level {
     PT_HD size_t n() const { return (size_t)shard_cap * 64u; }  // NSHARD = 64
     PT_HD float4 *rayA() const { return reinterpret_cast<float4 *>(base); }                  // (origin.xyz, dir.x)
     PT_HD float4 *rayB() const { return reinterpret_cast<float4 *>(base + 16 * n()); }       // (dir.y, dir.z, bits(rng key), bits(path node))
-    PT_HD float4 *coef() const { return reinterpret_cast<float4 *>(base + 32 * n()); }       // node coefficients (xyz, w)
+    PT_HD float4 *coef() const { return reinterpret_cast<float4 *>(base + 32 * n()); }       // node coefficients (xyz) and, in w, the node kind (pack_node)
     PT_HD float4 *val0() const { return rayA(); }                                            // radiance of child 0 (after shading)
     PT_HD float4 *val1() const { return rayB(); }                                            // radiance of child 1, the glass reflection (after shading)
     PT_HD uint32_t *parent() const { return reinterpret_cast<uint32_t *>(base + 48 * n()); } // (parent record index << 1) | child slot
     PT_HD uint32_t *hitprim() const { return reinterpret_cast<uint32_t *>(base + 52 * n()); } // nearest hit: primitive id | HIT_OUT_BIT if Transition::Out, or MISS
     PT_HD float *hit_t() const { return reinterpret_cast<float *>(base + 56 * n()); }        // its distance (with hitprim: two-kernel and trace-ahead pipelines)
-    PT_HD uint32_t *meta() const { return reinterpret_cast<uint32_t *>(base + 60 * n()); }   // node kind
-    static constexpr size_t RECORD_BYTES = 64;
+    static constexpr size_t RECORD_BYTES = 60;
 };
 
 struct PassParams {
@@ -442,6 +441,22 @@ __global__ __launch_bounds__(BLOCK) void k_rescan(DevScene sc, Level L, PassPara
 //     slot (a black terminal light sample, a leaf child of the trace-ahead pipeline, or children on the last level,
 //     which k_terminal pushes).
 constexpr uint32_t NO_CHILD = 0xFFFFFFFFu;
+// A node's kind travels in the fourth word of its coefficients: only a diffuse node uses that word as a number (the
+// cosine of reference src/tracer.rs:567), every other kind stores a tag there - the bit pattern of a SIGNALLING NaN,
+// which no arithmetic instruction can return (the cosine is the result of an addition: were it a NaN it would be a quiet
+// one), so a diffuse node's cosine is never mistaken for a tag.  The word is only ever moved and compared as bits.
+constexpr uint32_t KIND_TAG = 0x7FA00000u;
+__device__ __forceinline__ float4 pack_node(uint32_t kind, V3 coef, float coef_w) {
+    const uint32_t w = kind == NK_DIFFUSE ? f2u(coef_w) : (KIND_TAG | kind);
+    return make_float4(coef.x, coef.y, coef.z, u2f(w));
+}
+__device__ __forceinline__ uint32_t node_kind(float4 c) {
+    const uint32_t w = f2u(c.w);
+    return (w & 0xFFFFFFF8u) == KIND_TAG ? (w & 7u) : (uint32_t)NK_DIFFUSE;
+}
+// A leaf of an even level >= 2 hands its radiance to its parent at once and leaves this in the word that holds an inner
+// node's first child (hitprim), which is how the sweep tells it from a node it has to evaluate.
+constexpr uint32_t LEAF_DONE = 0xFFFFFFFEu;
 __device__ __forceinline__ bool pulled_level(uint32_t level) { return (level & 1u) != 0u; }
 __device__ __forceinline__ void remember_children(const Level &L, uint32_t i, uint32_t kind, uint32_t last_traced, bool has0, bool has1,
                                                   uint32_t i0, uint32_t i1) {
@@ -460,8 +475,8 @@ __device__ __forceinline__ V3 child_radiance(const Level &L, const Level &Lup, u
         float4 v = slot ? ld_stream(&L.val1()[i]) : ld_stream(&L.val0()[i]);
         return v3(v.x, v.y, v.z);
     }
-    uint32_t kind = ld_stream(&Lup.meta()[c]);
     float4 k = ld_stream(&Lup.coef()[c]);
+    const uint32_t kind = node_kind(k);
     if (kind == NK_LEAF) return v3(k.x, k.y, k.z);
     float4 a = ld_stream(&Lup.val0()[c]);
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -522,19 +537,15 @@ __device__ __forceinline__ void shade_record(const DevScene &sc, const Level &L,
             out.coef = node_value(out.kind, out.coef, out.coef_w, zero, zero);
             out.kind = NK_LEAF;
         }
-        if (out.kind == NK_LEAF) {
-            if (level == 0 || pulled_level(level)) {  // read where it is: by the resolve step, or by the level below
-                st_stream(&L.coef()[i], make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f));
-            } else {
-                // (the parent link is fetched only here: in closed scenes few records are leaves)
-                const uint32_t par = L.parent()[i];
-                float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
-                if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
-            }
-        } else {
-            st_stream(&L.coef()[i], make_float4(out.coef.x, out.coef.y, out.coef.z, out.coef_w));
+        if (out.kind == NK_LEAF && level != 0 && !pulled_level(level)) {
+            // (the parent link is fetched only here: in closed scenes few records are leaves)
+            const uint32_t par = L.parent()[i];
+            float4 v = make_float4(out.coef.x, out.coef.y, out.coef.z, 0.0f);
+            if (par & 1u) Lprev.val1()[par >> 1] = v; else Lprev.val0()[par >> 1] = v;
+            st_stream(&L.hitprim()[i], LEAF_DONE);
+        } else {  // (a leaf of level 0 or of an odd level is read where it is: by the resolve step, or by the level below)
+            st_stream(&L.coef()[i], pack_node(out.kind, out.coef, out.coef_w));
         }
-        st_stream(&L.meta()[i], out.kind);
     }
     PT_STAMP(4);  // sampling / BRDF arithmetic + node stores
     uint32_t i0, i1;
@@ -746,8 +757,7 @@ __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Le
             shade_prepare(lsc, o, d, prim, hit_t, hit_tr, nkey, c);
             shade_finish(c, d, nkey, out);
             // (only a primary ray can be a leaf here; the resolve step reads its radiance from coef)
-            L.coef()[i] = make_float4(out.coef.x, out.coef.y, out.coef.z, out.kind == NK_LEAF ? 0.0f : out.coef_w);
-            L.meta()[i] = out.kind;
+            L.coef()[i] = pack_node(out.kind, out.coef, out.coef_w);
         }
         bool has0 = valid && c.n_children >= 1, has1 = valid && c.n_children >= 2;
         uint32_t hp0 = MISS, hp1 = MISS;
@@ -952,9 +962,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lpre
     for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
         uint32_t i;
         if (!tile_record(m, L, w, i)) continue;
-        uint32_t kind = ld_stream(&L.meta()[i]);
-        if (kind == NK_LEAF) continue;
+        // On the last traced level most records are leaves (nodes whose terminal samples were all black): there the one
+        // word that says so is read first; elsewhere leaves are rare and everything is requested at once.
+        if (pull == 0u && ld_stream(&L.hitprim()[i]) == LEAF_DONE) continue;
         float4 c = ld_stream(&L.coef()[i]);
+        if (pull != 0u && ld_stream(&L.hitprim()[i]) == LEAF_DONE) continue;
+        const uint32_t kind = node_kind(c);
         V3 a = child_radiance(L, Lup, i, 0, pull != 0u);
         V3 b = v3(0.f, 0.f, 0.f);
         if (kind == NK_GLASS) b = child_radiance(L, Lup, i, 1, pull != 0u);
@@ -983,8 +996,8 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level 
 #pragma unroll 2
         for (uint32_t s = 0; s < spp; ++s) {
             uint32_t i = s * pp.n_pixels + pixel;
-            uint32_t kind = ld_stream(&L0.meta()[i]);
             float4 c = ld_stream(&L0.coef()[i]);
+            const uint32_t kind = node_kind(c);
             V3 value = v3(c.x, c.y, c.z);
             if (kind != NK_LEAF) {
                 V3 a = child_radiance(L0, L1, i, 0, pull != 0u);
