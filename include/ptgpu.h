@@ -171,8 +171,8 @@ int ptgpu_sync(PtHandle *h);
  * PTGPU_NOALLOC_SCRATCH_BYTES that is part of the loaded library (each GPU the library has run on holds one until the
  * process ends) instead of in memory the handle allocated, and the call makes no hipMalloc/hipFree and no host
  * allocation.  It returns when its samples are accumulated.
- * Limits: the queues of ONE sample per pixel must fit the array - about 167 000 pixels at max_depth 4 (e.g. 480x340),
- * 42 000 at max_depth 16, for levels of up to 1.25 records per sample (half of that when glass branches more) - else PT_ERR_INVALID_ARGUMENT; scenes traced through a BVH (by default those with
+ * Limits: the queues of ONE sample per pixel must fit the array - about 180 000 pixels at max_depth 4 (e.g. 480x375),
+ * 45 000 at max_depth 16, for levels of up to 1.25 records per sample (half of that when glass branches more) - else PT_ERR_INVALID_ARGUMENT; scenes traced through a BVH (by default those with
  * more than 100 primitives; PtConfig.accel = PT_ACCEL_BRUTE_FORCE keeps any scene on the linear scan) are refused likewise.  Glass
  * that branches beyond what fits gives PT_ERR_QUEUE_OVERFLOW (the samples that did fit are kept and counted).
  * All handles on one GPU share that GPU's array: calls that overlap on one GPU race; calls one after the other are

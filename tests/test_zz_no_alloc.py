@@ -104,15 +104,15 @@ def test_limits_are_errors(binding):
 
 
 def test_largest_image_that_fits(binding):
-    """400x400 pixels at max_depth 4 use 61 of the array's 64 MiB with one sample per pass: the carve reaches the far end
+    """424x424 pixels at max_depth 4 use 63.8 of the array's 64 MiB with one sample per pass: the carve reaches the far end
     of the array and the sums still equal ptgpu_render's.  (A closed room without glass: levels sized for one record
     per sample suffice.  The sample scene at this size overflows them through its glass sphere, would need levels twice
     as large, and is refused with PT_ERR_QUEUE_OVERFLOW.)"""
-    sc = S.diffuse_room_scene(400, 400)
+    sc = S.diffuse_room_scene(424, 424)
     (a32, a8, an, sa), (b32, b8, bn, sb) = _both(binding, sc, 3, max_depth=4)
     assert an == bn == 3 and np.array_equal(a32, b32) and np.array_equal(a8, b8) and sa["rays"] == sb["rays"]
     with binding.PtGpu() as gpu:
-        gpu.upload_scene(S.sample_scene(400, 400))
+        gpu.upload_scene(S.sample_scene(424, 424))
         with pytest.raises(binding.PtGpuError) as e:
             gpu.render_noalloc(1)
         assert e.value.code == -5
