@@ -48,9 +48,18 @@ def combine_accumulators(gpu, local_samples: int):
     n_words = gpu.width * gpu.height * 3
     buf = torch.empty(n_words, dtype=torch.int32, device=torch.device("cuda", gpu.cfg.device))
     gpu.export_pixels32(buf.data_ptr())
-    allreduce_sum_(buf)
-    total = torch.tensor([local_samples], dtype=torch.int64, device=buf.device)
-    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    if dist.get_backend() == "nccl":
+        allreduce_sum_(buf)
+        total = torch.tensor([local_samples], dtype=torch.int64, device=buf.device)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    else:
+        # a process group without device collectives (gloo: several ranks sharing one GPU, a debugging set-up): the
+        # same sums through host memory
+        host = buf.cpu()
+        allreduce_sum_(host)
+        buf.copy_(host)
+        total = torch.tensor([local_samples], dtype=torch.int64)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize(buf.device)
     gpu.import_pixels32(buf.data_ptr(), int(total.item()))
     return int(total.item())
