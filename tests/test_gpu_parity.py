@@ -461,7 +461,7 @@ def test_present_gives_the_display_bytes(binding):
 def test_basic_operations_match_the_host(binding, oracle):
     """f32 square root and division compile to instruction sequences on the device (correctly rounded by default) and
     the u32 -> (0,1] mapping of random32 is a division by 2^32: random bit patterns of every class against the host's
-    IEEE results, bit for bit (profiles/debug/math_exhaustive.py runs the same over all 2^32 arguments)."""
+    IEEE results, bit for bit (tests/tools/math_exhaustive.py runs the same over all 2^32 arguments)."""
     rng = np.random.RandomState(9)
     a = rng.randint(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)
     b = rng.randint(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)

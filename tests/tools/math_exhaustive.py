@@ -1,6 +1,6 @@
 """One-off: the device's deterministic sin / cos / exp / acos against the oracle's for EVERY binary32 input (2^32 each),
 bit patterns compared; powf(x, y) for every x at the two exponents the path uses (5 and 1/2.2, given as fn 25 and 22).
-python profiles/debug/math_exhaustive.py [fn ...]   (0 sin, 1 cos, 3 exp, 4 acos, 25 pow(x,5), 22 pow(x,1/2.2), 6 sqrt, 8 random32 of the bit pattern;
+python tests/tools/math_exhaustive.py [fn ...]   (0 sin, 1 cos, 3 exp, 4 acos, 25 pow(x,5), 22 pow(x,1/2.2), 6 sqrt, 8 random32 of the bit pattern;
 7 = division: 2^32 pairs of random bit patterns, half of them with the divisor's exponent forced near the dividend's)"""
 import sys, time
 from concurrent.futures import ThreadPoolExecutor

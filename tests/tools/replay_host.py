@@ -2,7 +2,7 @@
 every logged ray is walked through the BVH by the traversal functions of the kernels compiled for the host
 (ptgpu_bvh_host_trace), which check every reference into the tree and every stack slot.  Prints the seeds whose rays
 leave the tree, differ from the oracle's answer or start at NaN.
-python profiles/debug/replay_host.py FIRST COUNT"""
+python tests/tools/replay_host.py FIRST COUNT"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

@@ -1,5 +1,5 @@
 """One-off soak of a randomised test over many more seeds than the suite runs:
-python profiles/debug/soak.py FIRST COUNT [scenes|calls|soups]"""
+python tests/tools/soak.py FIRST COUNT [scenes|calls|soups]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import test_gpu_fuzz as F
