@@ -40,13 +40,13 @@ constexpr int BLOCK = 256;
 
 struct Level {
     // One allocation per level, carved into SoA arrays of n = NSHARD * shard_cap records: the three 16-byte arrays
-    // first, then the four 4-byte ones.  Only the base is passed to the kernels (three Levels of ten pointers each
+    // first, then the three 4-byte ones.  Only the base is passed to the kernels (three Levels of ten pointers each
     // cost 60 scalar registers and pushed the fused kernel into spilling them); the accessors below rebuild the
     // array addresses with a few scalar instructions.
     //
     // A record's ray is dead once the record has been shaded, and its children's radiance only arrives after that
     // (from the next level's launch, the terminal kernel or the backward sweep): the two share storage.  val0 is
-    // rayA's array and val1 rayB's, which is what keeps a record at 64 bytes.
+    // rayA's array and val1 rayB's; with the node kind inside coef's fourth word (pack_node) a record is 60 bytes.
     char *base;
     uint32_t *count;    // [NSHARD * CSTRIDE] records per shard, shard q at count[q * CSTRIDE]
     uint32_t *overflow; // this pass's flag: set when an append found a level full (the pass is then not accumulated)
