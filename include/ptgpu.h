@@ -225,6 +225,14 @@ int ptgpu_bvh_build_stats(const PtSceneDesc *scene, PtStats *out);
  * [3] = units fetched (faults points at four words).  A diagnostic for tests: it answers "which primitive" for any ray, including rays no scene
  * produces, without a GPU to fault. */
 int ptgpu_bvh_host_trace(const PtSceneDesc *scene, uint64_t n_rays, const float *rays, uint32_t *prims, float *ts, uint64_t *faults);
+/* The same with test switches.  PT_HOST_TRACE_UNGATED: the traversal normally answers rays it cannot walk safely by
+ * arithmetic alone (NaN or infinite origins and directions, origins far outside the structure) with the linear scan
+ * instead; with this flag EVERY ray is walked through the structure.  prims/ts may then differ from find_scene_hit's
+ * (src/scene.rs:263-297) for such rays, but faults[0] and faults[2] must still be 0: the walk follows only references the
+ * builder wrote (each node carries its child count), so it cannot leave the structure whatever the arithmetic yields. */
+enum { PT_HOST_TRACE_UNGATED = 1 };
+int ptgpu_bvh_host_trace_flags(const PtSceneDesc *scene, uint64_t n_rays, const float *rays, uint32_t *prims, float *ts, uint64_t *faults,
+                               uint32_t flags);
 const char *ptgpu_last_error(PtHandle *h);
 
 /* ---- Several GPUs of one node behind one handle ----------------------------------------------------------------

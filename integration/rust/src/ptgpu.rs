@@ -36,6 +36,8 @@ pub const PT_ACCEL_AUTO: i32 = 0;
 pub const PT_ACCEL_BRUTE_FORCE: i32 = 1;
 pub const PT_ACCEL_BVH: i32 = 2;
 
+pub const PT_HOST_TRACE_UNGATED: u32 = 1;
+
 pub const PT_KERNEL_RAYGEN: usize = 0;
 pub const PT_KERNEL_TRACE: usize = 1;
 pub const PT_KERNEL_SHADE: usize = 2;
@@ -195,6 +197,7 @@ extern "C" {
     pub fn ptgpu_get_stats(h: *mut PtHandle, out: *mut PtStats) -> i32;
     pub fn ptgpu_bvh_build_stats(scene: *const PtSceneDesc, out: *mut PtStats) -> i32;
     pub fn ptgpu_bvh_host_trace(scene: *const PtSceneDesc, n_rays: u64, rays: *const f32, prims: *mut u32, ts: *mut f32, faults: *mut u64) -> i32;
+    pub fn ptgpu_bvh_host_trace_flags(scene: *const PtSceneDesc, n_rays: u64, rays: *const f32, prims: *mut u32, ts: *mut f32, faults: *mut u64, flags: u32) -> i32;
     pub fn ptgpu_last_error(h: *mut PtHandle) -> *const c_char;
 
     pub fn ptgpu_group_create(cfg: *const PtConfig, devices: *const i32, n_devices: u32, out: *mut *mut PtGroup) -> i32;

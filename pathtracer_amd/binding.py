@@ -130,6 +130,9 @@ def load_library() -> C.CDLL:
     lib.ptgpu_bvh_build_stats.restype = C.c_int
     lib.ptgpu_bvh_host_trace.argtypes = [C.POINTER(PtSceneDesc), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.ptgpu_bvh_host_trace.restype = C.c_int
+    lib.ptgpu_bvh_host_trace_flags.argtypes = [C.POINTER(PtSceneDesc), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                               C.c_uint32]
+    lib.ptgpu_bvh_host_trace_flags.restype = C.c_int
     lib.ptgpu_last_error.argtypes = [H]
     lib.ptgpu_last_error.restype = C.c_char_p
     lib.ptgpu_camera_new.argtypes = [PtVec3, PtVec3, PtVec3, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_float,
@@ -212,17 +215,21 @@ def bvh_build_stats(scene: S.Scene) -> dict:
                                              "bvh_forced_median_splits", "bvh_level_fold")}
 
 
-def bvh_host_trace(scene: S.Scene, rays: np.ndarray):
+HOST_TRACE_UNGATED = 1
+
+
+def bvh_host_trace(scene: S.Scene, rays: np.ndarray, flags: int = 0):
     """Nearest primitive and distance for each ray (rows of origin.xyz, direction.xyz), found by the kernels' traversal
     functions compiled for the CPU (host only: works without a GPU), and the checker's counts: (prims, ts, faults) with
-    faults = dict(bad_units, bad_kinds, bad_slots, steps)."""
+    faults = dict(bad_units, bad_kinds, bad_slots, steps).  flags = HOST_TRACE_UNGATED walks every ray through the tree,
+    also those the traversal normally leaves to the linear scan."""
     sd = SceneDesc(scene)
     rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
     n = rays.shape[0]
     prims = np.empty(n, dtype=np.uint32)
     ts = np.empty(n, dtype=np.float32)
     faults = (C.c_uint64 * 4)()
-    rc = load_library().ptgpu_bvh_host_trace(C.byref(sd.desc), n, rays.ctypes.data, prims.ctypes.data, ts.ctypes.data, faults)
+    rc = load_library().ptgpu_bvh_host_trace_flags(C.byref(sd.desc), n, rays.ctypes.data, prims.ctypes.data, ts.ctypes.data, faults, flags)
     if rc != 0:
         raise PtGpuError(rc, "ptgpu_bvh_host_trace failed")
     return prims, ts, dict(bad_units=int(faults[0]), bad_kinds=int(faults[1]), bad_slots=int(faults[2]), steps=int(faults[3]))

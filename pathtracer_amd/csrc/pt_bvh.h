@@ -20,8 +20,13 @@
 // primitive (the plane's four vectors or the sphere's one, primitive id in the last word: four loads).  The up to four
 // children of a node occupy consecutive units, so a node names them by the index of the first:
 //   word  0..2   origin of the node's grid (x, y, z; f32)
-//   word  3      byte 0..2: binary exponents ex, ey, ez of the grid's cell size (signed); byte 3: bit i set = child i is
-//                a leaf primitive
+//   word  3      byte 0..2: binary exponents ex, ey, ez of the grid's cell size (signed); byte 3: bit i (i < 4) set = child i
+//                is a leaf primitive; its two top bits say which children are MISSING: 00 none (four children), 10 child
+//                3, 11 children 2 and 3 (a node has 2, 3 or 4 children, 0 .. n-1).  The traversal never enters or pushes a
+//                missing child, whatever the slab arithmetic says of its inside-out box (NaN distances, or a ray so far
+//                away that 255 cells vanish in the rounding, read as "enter"): every reference it follows is one the
+//                builder wrote, which is what keeps a walk inside the tree BY CONSTRUCTION.  (A tree whose root has fewer
+//                than two children - one primitive or none - is not walked at all, see bvh_begin.)
 //   word  4..9   the children's boxes on that grid, 8 bits a coordinate: words 4, 5 = x (child 0 and 1, child 2 and 3),
 //                6, 7 = y, 8, 9 = z; a child's 16 bits are lo | hi << 8.  A child that does not exist has lo = 255,
 //                hi = 0: no ray that bvh_begin lets into the tree enters it
@@ -63,6 +68,7 @@ constexpr uint32_t BVH_TRAV_BLOCKS = 2048;  // most blocks a traversing kernel i
 struct BvhHostCheck {
     const uint32_t *unit_prim = nullptr;   // per unit: primitive id of a leaf unit, MISS for a node (BvhBuilder::unit_prim)
     uint64_t bad_units = 0, bad_kinds = 0, bad_slots = 0;
+    bool ungated = false;   // test hook: bvh_begin lets EVERY ray into the tree (answers may then be wrong; references must not be)
 };
 inline BvhHostCheck &bvh_host_check() { static thread_local BvhHostCheck c; return c; }   // (host code only)
 
@@ -232,8 +238,14 @@ PT_HD void bvh_begin(const DevScene &sc, V3 o, V3 d, Trav &s) {
     // that has already met a NaN distance among the primitives outside the tree: the walk ends before it starts.
     // (sums, not maxima: a NaN or an infinity in any coordinate must fail the comparison)
     const float ao = (__builtin_fabsf(o.x) + __builtin_fabsf(o.y)) + __builtin_fabsf(o.z), ad = (__builtin_fabsf(d.x) + __builtin_fabsf(d.y)) + __builtin_fabsf(d.z);
-    const bool tame = ao <= sc.bvh_reach && ad <= 2.0f;
+    bool tame = ao <= sc.bvh_reach && ad <= 2.0f;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (bvh_host_check().ungated) tame = true;
+#endif
     if (!tame) s.best_out |= BVH_RESCAN;
+    // (a tree of fewer than three units - nothing or one primitive to bound - has a root with fewer than two children,
+    // which node_keys does not expect: the scan over that one primitive is the whole answer)
+    if (sc.n_bvh_units < 3u) s.best_out |= BVH_RESCAN;
     s.node = (s.best_out & BVH_RESCAN) ? BVH_EMPTY : 0;
 }
 
@@ -266,7 +278,8 @@ PT_HD void slab_pair(uint32_t w, uint32_t sel, float A, float B, float &n0, floa
 }
 
 // The four keys of a node for a ray: key = entry distance of a child the ray must visit, +inf otherwise.  A child that
-// does not exist is never entered: its box is inside out (which is only safe for the rays bvh_begin lets in).
+// does not exist (only children 2 and 3 can be missing: the two top bits of the meta word, read as one unsigned comparison
+// each) always gets +inf: its inside-out box alone keeps out only the rays whose slab distances are numbers.
 PT_HD void node_keys(const Trav &s, float4 q0, float4 q1, float4 q2, float &k0, float &k1, float &k2, float &k3) {
     const uint32_t meta = f2u(q0.w);
     const float Ax = __builtin_ldexpf(s.inv.x, (int)(int8_t)(meta & 0xffu)), Bx = __builtin_fmaf(q0.x, s.inv.x, s.noi.x);
@@ -287,8 +300,8 @@ PT_HD void node_keys(const Trav &s, float4 q0, float4 q1, float4 q2, float &k0, 
     const float tn3 = fmaxf(fmaxf(nx3, ny3), fmaxf(nz3, 0.0f)), tf3 = fminf(fminf(fx3, fy3), fz3) * WIDEN;
     k0 = tn0 <= fminf(tf0, s.best_t) ? tn0 : INF;
     k1 = tn1 <= fminf(tf1, s.best_t) ? tn1 : INF;
-    k2 = tn2 <= fminf(tf2, s.best_t) ? tn2 : INF;
-    k3 = tn3 <= fminf(tf3, s.best_t) ? tn3 : INF;
+    k2 = (meta < 0xC0000000u && tn2 <= fminf(tf2, s.best_t)) ? tn2 : INF;
+    k3 = (meta < 0x80000000u && tn3 <= fminf(tf3, s.best_t)) ? tn3 : INF;
 }
 
 // One step of an unfinished traversal (s.node != BVH_EMPTY): one fetch of the unit the lane stands on, then either the
@@ -310,8 +323,11 @@ PT_HD uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk, bool 
         if (outside) { s.node = BVH_EMPTY; return 0u; }
     }
 #endif
-    // (the shift drops bit 31; a 32-bit offset from a base all lanes share keeps the base in scalar registers)
-    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.bvh_nodes) + (size_t)((uint32_t)s.node << 6));
+    // (the shift drops bit 31; a 32-bit offset from a base all lanes share keeps the base in scalar registers).  The
+    // offset is clamped to the last unit: with child counts in the nodes no reference outside the tree can arise, and
+    // should one arise all the same (a damaged image) the fetch still stays inside the allocation.
+    const uint32_t last_unit = (sc.n_bvh_units - 1u) << 6, at = (uint32_t)s.node << 6;
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.bvh_nodes) + (size_t)(at < last_unit ? at : last_unit));
     float4 q0 = p[0], q1 = p[1], q2 = p[2];
     float4 q3;
     q3.x = 0.0f;   // (named by the statement below for every lane)
@@ -336,7 +352,7 @@ PT_HD uint32_t bvh_step(const DevScene &sc, Trav &s, const TravStack &stk, bool 
         pop = kj == INF;
         if (!pop) {
             const uint32_t base = f2u(q2.z);
-            const uint32_t leaf = meta >> 24;   // bit i: child i is a leaf primitive
+            const uint32_t leaf = meta >> 24;   // bit i (i < 4): child i is a leaf primitive (the bits above: missing children)
             const int32_t c0 = (int32_t)((base + 0u) | ((leaf & 1u) << 31)), c1 = (int32_t)((base + 1u) | ((leaf & 2u) << 30));
             const int32_t c2 = (int32_t)((base + 2u) | ((leaf & 4u) << 29)), c3 = (int32_t)((base + 3u) | ((leaf & 8u) << 28));
             // the others in fixed order; entries are culled by distance again when they are popped

@@ -365,7 +365,7 @@ struct BvhBuilder {
         for (int j = 0; j < n; ++j) if (bn[ch[j]].left < 0) leaf_bits |= 1u << j;
         uint32_t w[16] = {};
         std::memcpy(&w[0], org, 12);
-        w[3] = (uint32_t)(uint8_t)(int8_t)ex[0] | (uint32_t)(uint8_t)(int8_t)ex[1] << 8 | (uint32_t)(uint8_t)(int8_t)ex[2] << 16 | leaf_bits << 24;
+        w[3] = (uint32_t)(uint8_t)(int8_t)ex[0] | (uint32_t)(uint8_t)(int8_t)ex[1] << 8 | (uint32_t)(uint8_t)(int8_t)ex[2] << 16 | leaf_bits << 24 | (n >= 4 ? 0u : (n == 3 ? 2u : 3u)) << 30;
         for (int d = 0; d < 3; ++d)
             for (int half = 0; half < 2; ++half) {
                 const int j0 = 2 * half, j1 = 2 * half + 1;
@@ -452,6 +452,9 @@ struct BvhBuilder {
             if (depth > BVH_STACK || (size_t)unit >= unit_prim.size() || unit_prim[unit] != MISS_ID) { ++bad; return all; }
             uint32_t w[16];
             std::memcpy(w, &units[4 * (size_t)unit], 64);
+            // children the node says it has (its "missing" bits): a tree of at least three units has none with fewer than two
+            const uint32_t missing = w[3] >> 30, n_children = missing == 0u ? 4u : (missing == 2u ? 3u : 2u);
+            if (missing == 1u) ++bad;
             float org[3];
             std::memcpy(org, w, 12);
             for (int j = 0; j < 4; ++j) {
@@ -462,10 +465,13 @@ struct BvhBuilder {
                     qlo[d] = (int)(pair & 0xffu); qhi[d] = (int)(pair >> 8);
                     if (qlo[d] > qhi[d]) exists = false;
                 }
+                // the node's own count and its inside-out boxes must agree (children 0 and 1 are never marked missing: only
+                // the root of a tree of one or no primitive lacks them, and such a tree is not walked)
+                if (exists != ((uint32_t)j < n_children) && (unit_prim.size() >= 3 || j >= 2)) { ++bad; continue; }
                 if (!exists) continue;
                 const uint32_t child = w[10] + (uint32_t)j;
                 FBox sub;
-                if ((w[3] >> (24 + j)) & 1u) {
+                if ((w[3] >> (24 + j)) & 1u) {   // (bits 24..27: leaf children)
                     if ((size_t)child >= unit_prim.size() || unit_prim[child] == MISS_ID) { ++bad; continue; }
                     const Box &b = pbox[unit_prim[child]];
                     for (int d = 0; d < 3; ++d) { sub.lo[d] = down(b.lo[d] - pad); sub.hi[d] = up(b.hi[d] + pad); }

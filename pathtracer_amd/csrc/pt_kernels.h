@@ -165,6 +165,15 @@ __device__ __forceinline__ void wave_resolve(const Level &L, uint32_t shard, con
 // nobody wrote.  No kernel may consume them: every kernel of a pass returns at once when the pass's flag is already up
 // (it is raised by an EARLIER launch of the same stream, or by this one, whose stragglers then merely stop early).
 __device__ __forceinline__ bool pass_voided(const Level &L) { return __builtin_nontemporal_load(L.overflow) != 0u; }
+// The same decision for kernels whose blocks meet at a barrier: there it has to be ONE decision per block.  The flag may be
+// raised by another block of the same launch at any moment, so waves that each read it for themselves can disagree, and a
+// wave that leaves before a barrier the others wait at is undefined behaviour (and the ones that stay would read shared
+// memory the leavers never filled).  Thread 0 reads the flag once and publishes it through shared memory; the caller's
+// own barrier (the one that publishes the rest of its shared data) makes it visible, after which every thread of the
+// block takes the same branch.
+#define PT_BLOCK_VOID_DECL __shared__ uint32_t s_pass_void
+#define PT_BLOCK_VOID_READ(L) do { if (threadIdx.x == 0) s_pass_void = __builtin_nontemporal_load((L).overflow); } while (0)
+#define PT_BLOCK_VOIDED (s_pass_void != 0u)
 
 __device__ __forceinline__ uint32_t my_shard() { return (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (NSHARD - 1); }
 __device__ __forceinline__ uint32_t wave_global() { return blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); }
@@ -299,10 +308,12 @@ static_assert((DYN_LEAF_EVERY & (DYN_LEAF_EVERY - 1)) == 0 && DYN_STEPS % DYN_LE
 template <bool RAYGEN>
 __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc, Level L, PassParams pp, Counters *ctr) {
     __shared__ uint32_t s_incl[NSHARD], s_cnt[NSHARD];
-    if (pass_voided(L)) return;
+    PT_BLOCK_VOID_DECL;
+    PT_BLOCK_VOID_READ(L);
     TileMap m = tile_map(L);
     if (threadIdx.x < NSHARD) { s_incl[threadIdx.x] = m.incl; s_cnt[threadIdx.x] = m.cnt; }
     __syncthreads();
+    if (PT_BLOCK_VOIDED) return;
     const TravStack stk = trav_stack(sc);
 #ifdef PT_TRAV_STATS
     unsigned long long n_steps = 0, n_slots = 0, n_leaf = 0, ray_steps = 0, max_steps = 0;
@@ -579,18 +590,20 @@ template <bool FUSED, bool RAYGEN, bool LDS_SCENE, bool BVH, bool DEFER = false>
 __global__ __launch_bounds__(BLOCK, (BVH && FUSED) ? 4 : PT_SHADE_WAVES) void k_shade(DevScene sc, Level L, Level Lprev, Level Lnext, PassParams pp, uint32_t level,
                                                  uint32_t last_traced, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
-    if (pass_voided(L)) return;
+    PT_BLOCK_VOID_DECL;
     DevScene lsc = sc;  // what the shading step reads
     if (LDS_SCENE) {
+        PT_BLOCK_VOID_READ(L);
         const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 4u * (sc.n_sph + sc.n_pl);
         for (uint32_t j = threadIdx.x; j < n_s; j += BLOCK) s_scene[j] = sc.sph[j];
         for (uint32_t j = threadIdx.x; j < n_p; j += BLOCK) s_scene[n_s + j] = sc.pln[j];
         for (uint32_t j = threadIdx.x; j < n_m; j += BLOCK) s_scene[n_s + n_p + j] = sc.mat[j];
         __syncthreads();
+        if (PT_BLOCK_VOIDED) return;   // (one decision per block, after its only barrier)
         lsc.sph = s_scene;
         lsc.pln = s_scene + n_s;
         lsc.mat = s_scene + n_s + n_p;
-    }
+    } else if (pass_voided(L)) return;   // (no barrier in this variant: a wave may decide for itself)
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();
 #ifdef PT_STAMPS
@@ -692,18 +705,20 @@ template <bool RAYGEN, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK, PT_AHEAD_WAVES) void k_ahead(DevScene sc, Level L, Level Lnext, PassParams pp, uint32_t level,
                                                                uint32_t last_traced, uint32_t *traced_count, Counters *ctr) {
     __shared__ float4 s_scene[LDS_SCENE ? LDS_SCENE_CAP : 1];
-    if (pass_voided(L)) return;
+    PT_BLOCK_VOID_DECL;
     DevScene lsc = sc;  // what the shading step reads
     if (LDS_SCENE) {
+        PT_BLOCK_VOID_READ(L);
         const uint32_t n_s = sc.n_sph, n_p = 4u * sc.n_pl, n_m = 4u * (sc.n_sph + sc.n_pl);
         for (uint32_t j = threadIdx.x; j < n_s; j += BLOCK) s_scene[j] = sc.sph[j];
         for (uint32_t j = threadIdx.x; j < n_p; j += BLOCK) s_scene[n_s + j] = sc.pln[j];
         for (uint32_t j = threadIdx.x; j < n_m; j += BLOCK) s_scene[n_s + n_p + j] = sc.mat[j];
         __syncthreads();
+        if (PT_BLOCK_VOIDED) return;   // (one decision per block, after its only barrier)
         lsc.sph = s_scene;
         lsc.pln = s_scene + n_s;
         lsc.mat = s_scene + n_s + n_p;
-    }
+    } else if (pass_voided(L)) return;   // (no barrier in this variant: a wave may decide for itself)
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();
     uint32_t n_traced = 0;  // nearest-hit queries of this wave (wave-uniform)
@@ -834,7 +849,10 @@ __global__ __launch_bounds__(BLOCK, PT_SHADE_WAVES) void k_shade_sorted(DevScene
     __shared__ float4 s_a[BLOCK], s_b[BLOCK];
     __shared__ uint2 s_c[BLOCK];
     __shared__ uint32_t s_cnt[BLOCK / 64][8];
-    if (pass_voided(L)) return;
+    PT_BLOCK_VOID_DECL;
+    PT_BLOCK_VOID_READ(L);
+    __syncthreads();
+    if (PT_BLOCK_VOIDED) return;   // (one decision per block: its steps below meet at barriers)
     TileMap m = tile_map(L);
     const uint32_t shard = my_shard();
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -983,7 +1001,9 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lpre
 // its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level L1, PassParams pp, uint32_t spp, uint32_t pull,
                                                   uint32_t *pixels32) {
-    if (*L0.overflow != 0u) return;  // a level overflowed somewhere in this pass: it adds nothing (the host repeats it)
+    // A level overflowed somewhere in this pass: it adds nothing (the host repeats it).  (No launch of the pass is still
+    // running when this one starts and it appends nothing itself, so every thread reads the same value.)
+    if (*L0.overflow != 0u) return;
     // the quantiser's threshold table is searched 24 times per sample with per-lane indices: keep it in LDS
     __shared__ float s_gamma[256];
     if (sc.gamma_table != nullptr) {

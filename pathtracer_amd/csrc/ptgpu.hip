@@ -115,24 +115,34 @@ struct PtHandle {
 namespace {
 
 int fail(PtHandle *h, int code, const std::string &msg) {
-    if (h) h->error = msg;
+    if (h) h->error.assign(msg);   // (copied into the text's own storage, which keeps its reserved room: see api_caught)
+    return code;
+}
+
+// No C++ exception may cross the C boundary (a std::bad_alloc from a scene-sized std::vector would reach a C, Rust or
+// ctypes caller as std::terminate): every entry point that returns a status runs between PT_API_BEGIN and PT_API_END.
+// Reports a fixed string; the handle's error text has room for it from creation on (ERROR_TEXT_RESERVE), so this
+// neither allocates nor throws.
+constexpr size_t ERROR_TEXT_RESERVE = 1024;
+int api_caught(PtHandle *h, int code, const char *what) noexcept {
+    try { if (h) h->error = what; } catch (...) { }
+    return code;
+}
+
+// A failed HIP call.  Inside ptgpu_render_noalloc (no_spans) only the call's own text is reported - composing a message
+// with the runtime's error string would allocate.
+int fail_hip(PtHandle *h, hipError_t e, const char *call) noexcept {
+    const int code = e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
+    if (!h || h->no_spans) return api_caught(h, code, call);
+    try { h->error.assign(std::string(call) + ": " + hipGetErrorString(e)); } catch (...) { return api_caught(h, code, call); }
     return code;
 }
 
 #define HIPCHK(h, call)                                                                                      \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
-        if (e_ != hipSuccess)                                                                                \
-            return fail(h, e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP,                    \
-                        std::string(#call) + ": " + hipGetErrorString(e_));                                  \
+        if (e_ != hipSuccess) return fail_hip(h, e_, #call);                                                 \
     } while (0)
-
-// No C++ exception may cross the C boundary (a std::bad_alloc from a scene-sized std::vector would reach a C, Rust or
-// ctypes caller as std::terminate): every entry point that returns a status runs between these two.
-int api_caught(PtHandle *h, int code, const char *what) noexcept {
-    try { if (h) h->error = what; } catch (...) { }
-    return code;
-}
 #define PT_API_BEGIN try {
 #define PT_API_END(h)                                                                                        \
     } catch (const std::bad_alloc &) { return api_caught(h, PT_ERR_OUT_OF_MEMORY, "host memory allocation failed"); \
@@ -694,6 +704,7 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
     if (!h) return PT_ERR_OUT_OF_MEMORY;
     h->cfg = *cfg;
     h->device = cfg->device;
+    h->error.reserve(ERROR_TEXT_RESERVE);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PT_ERR_HIP; }
     h->pipes[0].stream = h->stream;
     bool ok = true;
@@ -961,14 +972,16 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
 
 int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
     if (!h) return PT_ERR_INVALID_ARGUMENT;
+    // Everything below reports through fixed strings (api_caught): composing a message would allocate.  Nothing in the
+    // body allocates or throws by design; the handler is there so that nothing can cross the C boundary all the same.
+    try {
     if (!h->have_scene) return api_caught(h, PT_ERR_NO_SCENE, "no scene uploaded");
     if (!h->scratch_ptr) return api_caught(h, PT_ERR_INVALID_ARGUMENT, "ptgpu_render_noalloc: no static scratch on this device ordinal");
     if (h->sc.bvh_nodes)
         return api_caught(h, PT_ERR_INVALID_ARGUMENT,
-                          "ptgpu_render_noalloc: scenes traced through a BVH (more than 192 primitives, or PT_ACCEL_BVH) need a "
+                          "ptgpu_render_noalloc: scenes traced through a BVH (more than 100 primitives, or PT_ACCEL_BVH) need a "
                           "traversal spill area larger than the static scratch; use ptgpu_render");
     if (n_samples == 0) return PT_OK;
-    // Errors below are reported through fixed strings (api_caught): building a message would allocate.
 #define NA_HIP(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); h->no_spans = false; return api_caught(h, PT_ERR_HIP, "ptgpu_render_noalloc: " #call " failed"); } } while (0)
     NA_HIP(hipSetDevice(h->device));
     // passes of earlier ptgpu_render calls add into the same accumulator from other streams: let them finish (their
@@ -999,6 +1012,19 @@ int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
     h->sample_cursor += n_samples;
     bool planned = false;
     uint64_t lost = 0;   // samples of passes that overflowed and could not be repeated
+    Range launched[NOALLOC_FLAGS];
+    uint32_t flags[NOALLOC_FLAGS];
+    uint32_t n_launched = 0;
+    // Waits for the passes launched in this round and counts the samples of those that were accumulated, so that the
+    // accumulator and what it is divided by stay in step also when the call ends early; false: the device cannot be
+    // asked any more (then neither count means anything).
+    auto settle = [&]() -> bool {
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return false;
+        if (n_launched && hipMemcpy(flags, h->scratch_ptr + pl.flags_off, n_launched * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        for (uint32_t k = 0; k < n_launched; ++k)
+            if (!flags[k]) { h->local_samples += launched[k].count; h->num_samples += launched[k].count; }
+        return true;
+    };
     while (sp > 0) {
         if (!planned) {   // (re)carve the scratch for the current growth and pass size
             unsigned char *base = h->scratch_ptr;
@@ -1019,27 +1045,34 @@ int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
         }
         Range r = stack[--sp];
         // one round: up to NOALLOC_FLAGS passes of this range, each with its own overflow flag
-        Range launched[NOALLOC_FLAGS];
-        uint32_t n_launched = 0;
+        n_launched = 0;
         while (r.count > 0 && n_launched < NOALLOC_FLAGS) {
             const uint32_t k = std::min(spp, r.count);
             uint32_t *flag = (uint32_t *)(h->scratch_ptr + pl.flags_off) + n_launched;
             int rc = run_pass(h, pipe, nullptr, k, r.first, flag);
-            if (rc) { h->no_spans = false; return rc; }
+            if (rc) {   // (the passes already enqueued in this round still run and add their samples: count them)
+                (void)hipGetLastError();
+                (void)settle();
+                h->no_spans = false;
+                return rc;
+            }
             launched[n_launched++] = {r.first, k};
             r.first += k;
             r.count -= k;
         }
         if (r.count > 0) stack[sp++] = r;
-        uint32_t flags[NOALLOC_FLAGS];
-        NA_HIP(hipStreamSynchronize(h->stream));
-        NA_HIP(hipMemcpy(flags, h->scratch_ptr + pl.flags_off, n_launched * 4, hipMemcpyDeviceToHost));
+        if (!settle()) {
+            (void)hipGetLastError();
+            h->no_spans = false;
+            return api_caught(h, PT_ERR_HIP, "ptgpu_render_noalloc: waiting for the passes of this call failed");
+        }
         bool any = false;
         for (uint32_t k = 0; k < n_launched; ++k) {
-            if (!flags[k]) { h->local_samples += launched[k].count; h->num_samples += launched[k].count; continue; }
+            if (!flags[k]) continue;
             any = true;
             if (sp < STACK) stack[sp++] = launched[k]; else lost += launched[k].count;
         }
+        n_launched = 0;
         if (any) {   // glass branched beyond the levels: the voided passes are on the stack again; make room for twice the branching
             uint32_t next_spp = 0;
             if (!h->fixed_capacity && growth < (1u << 30)) {
@@ -1062,6 +1095,10 @@ int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
                           "ptgpu_render_noalloc: glass branching overflowed the queues that fit the static scratch; some samples of this "
                           "call were not accumulated (use ptgpu_render, a smaller image or a smaller max_depth)");
     return PT_OK;
+    } catch (...) {
+        h->no_spans = false;
+        return api_caught(h, PT_ERR_INTERNAL, "ptgpu_render_noalloc: unexpected C++ exception");
+    }
 }
 
 int ptgpu_sync(PtHandle *h) {
@@ -1249,6 +1286,10 @@ int ptgpu_bvh_build_stats(const PtSceneDesc *s, PtStats *out) {
 // The traversal functions of the kernels, compiled for the host, over caller-supplied rays: builds the tree for `s` and
 // walks it on the CPU, one ray after the other, with every unit reference and stack slot checked.
 int ptgpu_bvh_host_trace(const PtSceneDesc *s, uint64_t n_rays, const float *rays, uint32_t *prims, float *ts, uint64_t *faults) {
+    return ptgpu_bvh_host_trace_flags(s, n_rays, rays, prims, ts, faults, 0u);
+}
+
+int ptgpu_bvh_host_trace_flags(const PtSceneDesc *s, uint64_t n_rays, const float *rays, uint32_t *prims, float *ts, uint64_t *faults, uint32_t flags) {
     PT_API_BEGIN
     if (!s || (n_rays && (!rays || !prims || !ts)) || !faults) return PT_ERR_INVALID_ARGUMENT;
     if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_emissive_spheres && !s->emissive_spheres) ||
@@ -1279,6 +1320,7 @@ int ptgpu_bvh_host_trace(const PtSceneDesc *s, uint64_t n_rays, const float *ray
     BvhHostCheck &chk = bvh_host_check();
     chk = BvhHostCheck();
     chk.unit_prim = builder.unit_prim.data();
+    chk.ungated = (flags & PT_HOST_TRACE_UNGATED) != 0u;
     uint64_t steps = 0;
     for (uint64_t r = 0; r < n_rays; ++r) {
         Trav st;
@@ -1296,6 +1338,7 @@ int ptgpu_bvh_host_trace(const PtSceneDesc *s, uint64_t n_rays, const float *ray
     std::free(spill);
     faults[0] = chk.bad_units; faults[1] = chk.bad_kinds; faults[2] = chk.bad_slots; faults[3] = steps;
     chk.unit_prim = nullptr;
+    chk.ungated = false;
     return PT_OK;
     PT_API_END(nullptr)
 }

@@ -141,4 +141,10 @@ def test_rays_no_render_produces(oracle, name, sc):
         d[i] = 0.0; d[i, a[i]] = s
         o[i] = target[i]; o[i, a[i]] = -s * dist[i, 0]
     f = _check_against_linear_scan(sc, osc, np.concatenate([o, d], axis=1))
-    assert f["steps"] > 0
+    tiny = name in ("one sphere", "unboundable only")   # a tree of fewer than three units is not walked: its one primitive is scanned
+    assert (f["steps"] == 0) if tiny else (f["steps"] > 0)
+    # Safety by construction: with the gate off - every ray, NaN and infinite ones included, is walked through the tree, so
+    # the answers may differ from the scan's - the walk still follows only references the builder wrote (each node names
+    # how many children it has), ends, and keeps its stack in bounds.
+    _, _, g = binding.bvh_host_trace(sc, np.concatenate([o, d], axis=1), flags=binding.HOST_TRACE_UNGATED)
+    assert g["bad_units"] == 0 and g["bad_slots"] == 0 and g["steps"] >= f["steps"]

@@ -116,3 +116,29 @@ def test_largest_image_that_fits(binding):
         with pytest.raises(binding.PtGpuError) as e:
             gpu.render_noalloc(1)
         assert e.value.code == -5
+
+
+def _device_free_bytes():
+    """Free device memory as the HIP runtime reports it (hipMemGetInfo through the runtime libptgpu already loaded)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_the_call_takes_no_device_memory(binding):
+    """What the handle holds and what the device has free are the same before and after a call (the first call on a fresh
+    process is left out of the comparison: the runtime loads kernels and sets up their spill memory when they first run)."""
+    sc = materials_scene(48, 36)
+    with binding.PtGpu() as gpu:
+        gpu.upload_scene(sc)
+        gpu.render_noalloc(2)
+        gpu.sync()
+        held, free = gpu.stats()["device_bytes"], _device_free_bytes()
+        for spp in (70, 3):            # more than one pass, then a small call
+            gpu.render_noalloc(spp)
+            gpu.sync()
+            assert gpu.stats()["device_bytes"] == held
+            assert _device_free_bytes() == free
+        assert gpu.read_pixels32()[1] == 75
