@@ -164,6 +164,35 @@ int ptgpu_clear(PtHandle *h);
 int ptgpu_render(PtHandle *h, uint32_t n_samples);
 int ptgpu_sync(PtHandle *h);
 
+/* One iteration of the window loop - the tile fan-out + wait() of a frame AND the hand-over of Backbuffer.pixels8 to
+ * glDrawPixels (src/window.rs:166-213) - with the two pipelined: the call enqueues n_samples more samples per pixel
+ * (the reference's frame is 1: the literal of src/window.rs:166), whose last pass also writes the display bytes
+ * (assign_pixel8_unsafe, src/tracer.rs:271-282, for the sums and the sample count as they stand after this frame), and
+ * returns in *pixels the display bytes of the frame BEFORE it - complete by now, or nearly - in page-locked memory the
+ * library owns; *num_samples (may be NULL) = the samples per pixel that image shows.  The host draws one frame behind
+ * and never waits for the frame it has just asked for, and the GPU always has the next frame queued: a loop of
+ * ptgpu_render(h, 1) + ptgpu_present_pixels8 leaves the GPU idle while the host waits, copies and draws.
+ * Every image handed out is exactly Backbuffer.pixels8 after that many samples - the bytes ptgpu_read_pixels8 gives
+ * after the same number of ptgpu_render samples.  The first call after ptgpu_upload_scene / ptgpu_clear has no frame
+ * before it and waits for its own; n_samples == 0 renders nothing and returns the newest frame (a flush: the last
+ * image of a loop).  *pixels stays valid until the next call but one.  A frame is one pipeline pass when n_samples is at
+ * most the pass size (PtConfig.samples_per_batch; 0 = auto). */
+int ptgpu_frame(PtHandle *h, uint32_t n_samples, const uint8_t **pixels, uint64_t *num_samples);
+
+/* Tile shards - the other way to split the path over several handles (the first: PtConfig.shard_index / shard_count
+ * select sample indices, ptgpu_render).  The image is cut into the reference's 32x32 work tiles (src/window.rs:167-178;
+ * clipped to the image), tile (tile_x, tile_y) belongs to handle ptgpu_tile_shard(tile_x, tile_y, tiles_x, shard_count),
+ * and this call adds the global sample indices first_sample .. first_sample + n_samples - 1 for the pixels of THIS
+ * handle's tiles only (its other pixels keep their sums).  The counter RNG is keyed on (pixel, global sample index), so
+ * the sums of all shard_count handles, added up, are bit for bit what one handle renders for the same samples - and no
+ * handle needs another's data to show its own tiles: a frame of ONE sample keeps every GPU busy.  Calls of
+ * ptgpu_render and ptgpu_render_tiles may be mixed as long as every sample index is rendered once for every pixel. */
+enum { PT_TILE = 32 };
+int ptgpu_render_tiles(PtHandle *h, uint64_t first_sample, uint32_t n_samples);
+/* The split rule itself (pure arithmetic, no device): tile_id modulo n, rows shifted against each other when a row of
+ * tiles holds a whole number of rounds. */
+uint32_t ptgpu_tile_shard(uint32_t tile_x, uint32_t tile_y, uint32_t tiles_x, uint32_t n);
+
 /* ptgpu_render for callers that cannot allocate.  No counterpart in the reference: it exists for hosts that must not
  * call hipMalloc while they render - code under HIP graph capture, tight serving loops, harnesses that forbid it.
  * Same inputs (the uploaded scene) and outputs (the handle's accumulators, the same sample indices ptgpu_render would
@@ -250,9 +279,19 @@ int ptgpu_group_create(const PtConfig *cfg, const int32_t *devices, uint32_t n_d
 void ptgpu_group_destroy(PtGroup *g);
 int ptgpu_group_upload_scene(PtGroup *g, const PtSceneDesc *scene);   /* every `*scene = ...; backbuffer.clear()` site, src/window.rs:130-163 */
 int ptgpu_group_clear(PtGroup *g);                                    /* Backbuffer::clear, src/tracer.rs:242-256 */
-/* n_samples more samples per pixel IN TOTAL, split over the devices by sample index (src/window.rs:166-196 x n_samples);
- * returns when the work is enqueued on every device. */
+/* n_samples more samples per pixel IN TOTAL (src/window.rs:166-196 x n_samples), split over the devices by sample index
+ * - or, when there are fewer samples than devices (the window loop's one sample per frame), by image tile: every device
+ * renders all of them for its own 32x32 tiles (ptgpu_render_tiles), so no device idles.  Returns when the work is
+ * enqueued on every device. */
 int ptgpu_group_render(PtGroup *g, uint32_t n_samples);
+/* ptgpu_frame for the group: one iteration of the window loop (src/window.rs:166-213) on every GPU of the node.  The
+ * frame's n_samples are split by image tile, each device's last pass writes the display bytes of its own tiles, one RCCL
+ * exchange of bytes (ncclReduce of ncclUint8: disjoint tiles, a quarter of the size of the sums) gathers them on the first
+ * device, and the call returns the frame BEFORE this one from page-locked memory; no device waits for the host, no
+ * device waits for another's sums.  The images are exactly Backbuffer.pixels8 after *num_samples samples.  After a
+ * ptgpu_group_render that split by sample index (until the next clear) the frames are not pipelined: each call then
+ * renders, reduces the sums and returns its own frame. */
+int ptgpu_group_frame(PtGroup *g, uint32_t n_samples, const uint8_t **pixels, uint64_t *num_samples);
 int ptgpu_group_sync(PtGroup *g);
 /* Backbuffer.pixels32 / pixels8 / the bytes for glDrawPixels (src/window.rs:205-210) of everything rendered so far;
  * each call synchronises the devices and runs the one reduction. */

@@ -2,7 +2,8 @@
 //! renderer that owns either one GPU (PtHandle) or all GPUs of the node (PtGroup).
 //!
 //! The reference drives `WorkerPool::process(tile)` x tiles + `wait()` once per frame (src/window.rs:166-196) and
-//! shows `Backbuffer.pixels8` (:205-210).  `GpuRenderer::render_frame` + `present` are those two steps.
+//! shows `Backbuffer.pixels8` (:205-210).  `GpuRenderer::frame` is those two steps pipelined (the window shows the
+//! frame before the one it has just enqueued); `render_frame` + `present` are the same two steps one after the other.
 #![allow(dead_code)]
 
 use std::ffi::CStr;
@@ -107,8 +108,8 @@ pub struct GpuRenderer {
 }
 
 impl GpuRenderer {
-    /// `all_gpus = false`: device 0 through a PtHandle.  `true`: every visible GPU through a PtGroup (sample-index
-    /// shards, RCCL reduction at present).  Without an MI355X this fails with PT_ERR_NO_DEVICE: there is no CPU path.
+    /// `all_gpus = false`: device 0 through a PtHandle.  `true`: every visible GPU through a PtGroup (a frame is split
+    /// by 32x32 tile, larger calls by sample index; one RCCL exchange per image shown).  Without an MI355X this fails with PT_ERR_NO_DEVICE: there is no CPU path.
     pub fn new(all_gpus: bool) -> Result<GpuRenderer, GpuError> {
         unsafe {
             let mut cfg: PtConfig = std::mem::zeroed();
@@ -169,6 +170,21 @@ impl GpuRenderer {
             }
         };
         self.check(rc)
+    }
+
+    /// One iteration of the window loop (src/window.rs:166-213): enqueues `samples` more samples per pixel (the
+    /// reference's frame is 1) and returns the display bytes - `Backbuffer.pixels8` as glDrawPixels wants it: RGB8,
+    /// bottom row first - of the frame BEFORE this one, in the library's page-locked memory, valid until the next call
+    /// but one.  With all GPUs of the node each frame is split over them by 32x32 tile.
+    pub fn frame(&mut self, samples: u32) -> Result<*const u8, GpuError> {
+        let mut shown: *const u8 = ptr::null();
+        let rc = unsafe {
+            match self.backend {
+                Backend::One(h) => ptgpu_frame(h, samples, &mut shown, ptr::null_mut()),
+                Backend::Node(g) => ptgpu_group_frame(g, samples, &mut shown, ptr::null_mut()),
+            }
+        };
+        self.check(rc).map(|_| shown)
     }
 
     /// One frame of the reference = one sample per pixel over the whole image (src/window.rs:166-196).

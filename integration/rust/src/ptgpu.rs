@@ -37,6 +37,7 @@ pub const PT_ACCEL_BRUTE_FORCE: i32 = 1;
 pub const PT_ACCEL_BVH: i32 = 2;
 
 pub const PT_HOST_TRACE_UNGATED: u32 = 1;
+pub const PT_TILE: u32 = 32;
 
 pub const PT_KERNEL_RAYGEN: usize = 0;
 pub const PT_KERNEL_TRACE: usize = 1;
@@ -185,6 +186,9 @@ extern "C" {
     pub fn ptgpu_render(h: *mut PtHandle, n_samples: u32) -> i32;
     pub fn ptgpu_sync(h: *mut PtHandle) -> i32;
     pub fn ptgpu_render_noalloc(h: *mut PtHandle, n_samples: u32) -> i32;
+    pub fn ptgpu_frame(h: *mut PtHandle, n_samples: u32, pixels: *mut *const u8, num_samples: *mut u64) -> i32;
+    pub fn ptgpu_render_tiles(h: *mut PtHandle, first_sample: u64, n_samples: u32) -> i32;
+    pub fn ptgpu_tile_shard(tile_x: u32, tile_y: u32, tiles_x: u32, n: u32) -> u32;
     pub fn ptgpu_read_pixels32(h: *mut PtHandle, out: *mut u32, num_samples: *mut u64) -> i32;
     pub fn ptgpu_read_pixels8(h: *mut PtHandle, out: *mut u8) -> i32;
     pub fn ptgpu_present_pixels8(h: *mut PtHandle, pixels: *mut *const u8) -> i32;
@@ -205,6 +209,7 @@ extern "C" {
     pub fn ptgpu_group_upload_scene(g: *mut PtGroup, scene: *const PtSceneDesc) -> i32;
     pub fn ptgpu_group_clear(g: *mut PtGroup) -> i32;
     pub fn ptgpu_group_render(g: *mut PtGroup, n_samples: u32) -> i32;
+    pub fn ptgpu_group_frame(g: *mut PtGroup, n_samples: u32, pixels: *mut *const u8, num_samples: *mut u64) -> i32;
     pub fn ptgpu_group_sync(g: *mut PtGroup) -> i32;
     pub fn ptgpu_group_read_pixels32(g: *mut PtGroup, out: *mut u32, num_samples: *mut u64) -> i32;
     pub fn ptgpu_group_read_pixels8(g: *mut PtGroup, out: *mut u8) -> i32;

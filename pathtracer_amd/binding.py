@@ -92,6 +92,10 @@ def load_library() -> C.CDLL:
     lib.ptgpu_render.argtypes = [H, C.c_uint32]
     lib.ptgpu_sync.argtypes = [H]
     lib.ptgpu_render_noalloc.argtypes = [H, C.c_uint32]
+    lib.ptgpu_frame.argtypes = [H, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.ptgpu_render_tiles.argtypes = [H, C.c_uint64, C.c_uint32]
+    lib.ptgpu_tile_shard.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.ptgpu_tile_shard.restype = C.c_uint32
     lib.ptgpu_read_pixels32.argtypes = [H, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.ptgpu_read_pixels8.argtypes = [H, C.c_void_p]
     lib.ptgpu_present_pixels8.argtypes = [H, C.POINTER(C.c_void_p)]
@@ -109,6 +113,7 @@ def load_library() -> C.CDLL:
     lib.ptgpu_group_upload_scene.argtypes = [G, C.POINTER(PtSceneDesc)]
     lib.ptgpu_group_clear.argtypes = [G]
     lib.ptgpu_group_render.argtypes = [G, C.c_uint32]
+    lib.ptgpu_group_frame.argtypes = [G, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.ptgpu_group_sync.argtypes = [G]
     lib.ptgpu_group_read_pixels32.argtypes = [G, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.ptgpu_group_read_pixels8.argtypes = [G, C.c_void_p]
@@ -123,7 +128,7 @@ def load_library() -> C.CDLL:
     lib.ptgpu_group_member.restype = C.c_void_p
     lib.ptgpu_group_last_error.argtypes = [G]
     lib.ptgpu_group_last_error.restype = C.c_char_p
-    for name in ("create", "upload_scene", "clear", "render", "sync", "read_pixels32", "read_pixels8", "present_pixels8", "get_stats",
+    for name in ("create", "upload_scene", "clear", "render", "frame", "sync", "read_pixels32", "read_pixels8", "present_pixels8", "get_stats",
                  "exchange_stats"):
         getattr(lib, "ptgpu_group_" + name).restype = C.c_int
     lib.ptgpu_bvh_build_stats.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtStats)]
@@ -147,7 +152,7 @@ def load_library() -> C.CDLL:
     for name in ("ptgpu_create", "ptgpu_upload_scene", "ptgpu_clear", "ptgpu_render", "ptgpu_sync", "ptgpu_read_pixels32",
                  "ptgpu_read_pixels8", "ptgpu_render_primary_ids", "ptgpu_device_pixels32", "ptgpu_set_num_samples",
                  "ptgpu_stream", "ptgpu_get_stats", "ptgpu_eval_math", "ptgpu_export_pixels32", "ptgpu_import_pixels32", "ptgpu_selftest_gamma",
-                 "ptgpu_present_pixels8", "ptgpu_render_noalloc"):
+                 "ptgpu_present_pixels8", "ptgpu_render_noalloc", "ptgpu_frame", "ptgpu_render_tiles"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -235,6 +240,11 @@ def bvh_host_trace(scene: S.Scene, rays: np.ndarray, flags: int = 0):
     return prims, ts, dict(bad_units=int(faults[0]), bad_kinds=int(faults[1]), bad_slots=int(faults[2]), steps=int(faults[3]))
 
 
+def tile_shard(tile_x: int, tile_y: int, tiles_x: int, n: int) -> int:
+    """Which of n tile shards owns 32x32 tile (tile_x, tile_y) of an image tiles_x tiles wide (pure arithmetic, no GPU)."""
+    return int(load_library().ptgpu_tile_shard(tile_x, tile_y, tiles_x, n))
+
+
 def _stats_dict(st: PtStats) -> dict:
     return {
         "samples": st.samples, "rays": st.rays, "shadow_rays": st.shadow_rays, "records": st.records, "terminal_records": st.terminal_records, "bvh_nodes": st.bvh_nodes,
@@ -302,6 +312,14 @@ class PtGroup:
 
     def render(self, n_samples: int) -> None:
         self._chk(self.lib.ptgpu_group_render(self.g, int(n_samples)))
+
+    def frame(self, n_samples: int = 1):
+        """One iteration of the window loop on all GPUs (ptgpu_group_frame): enqueues n_samples, returns (display bytes of the
+        frame before - a view of page-locked memory valid until the next call but one -, samples per pixel they show)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.ptgpu_group_frame(self.g, int(n_samples), C.byref(p), C.byref(n)))
+        buf = (C.c_uint8 * (self.height * self.width * 3)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3), int(n.value)
 
     def sync(self) -> None:
         self._chk(self.lib.ptgpu_group_sync(self.g))
@@ -379,6 +397,19 @@ class PtGpu:
 
     def render(self, n_samples: int) -> None:
         self._chk(self.lib.ptgpu_render(self.h, int(n_samples)))
+
+    def render_tiles(self, first_sample: int, n_samples: int) -> None:
+        """Global sample indices first_sample .. first_sample + n_samples - 1 for the pixels of this handle's 32x32 tiles
+        (tile shards: shard_index of shard_count by ptgpu_tile_shard)."""
+        self._chk(self.lib.ptgpu_render_tiles(self.h, int(first_sample), int(n_samples)))
+
+    def frame(self, n_samples: int = 1):
+        """One iteration of the window loop (ptgpu_frame): enqueues n_samples, returns (display bytes of the frame before - a
+        view of page-locked memory valid until the next call but one -, samples per pixel they show)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.ptgpu_frame(self.h, int(n_samples), C.byref(p), C.byref(n)))
+        buf = (C.c_uint8 * (self.height * self.width * 3)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3), int(n.value)
 
     def render_noalloc(self, n_samples: int) -> None:
         """ptgpu_render with its ray queues in the library's static device array: no allocation during the call."""

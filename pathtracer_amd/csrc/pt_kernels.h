@@ -64,9 +64,12 @@ struct Level {
 };
 
 struct PassParams {
-    uint32_t n_pixels;        // P
+    uint32_t n_pixels;        // pixels this pass renders: all P of the image, or the pixels of this handle's tiles (pixel_map)
     uint32_t sample_first;    // global sample index of local sample 0 of this pass
-    uint32_t sample_stride;   // shard_count
+    uint32_t sample_stride;   // sample-index shards: shard_count; tile shards: 1
+    const uint32_t *pixel_map;  // tile shards: [n_pixels] the image pixel (y * width + x) of the pass's k-th pixel - the handle's 32x32
+                                // tiles one after the other, row-major inside a tile, so that a wave of 64 level-0 records is two rows
+                                // of one tile; null: the identity
 };
 
 // device-side counters (one allocation)
@@ -179,11 +182,8 @@ __device__ __forceinline__ uint32_t my_shard() { return (blockIdx.x * (BLOCK / 6
 __device__ __forceinline__ uint32_t wave_global() { return blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t waves_in_grid() { return gridDim.x * (BLOCK / 64); }
 
-// Counter-RNG key of a pixel-sample; `sid` = local sample * n_pixels + pixel is the level-0 record index.
-__device__ __forceinline__ uint32_t sample_key_of(const DevScene &sc, const PassParams &pp, uint32_t sid) {
-    uint32_t pixel = sid % pp.n_pixels, s_local = sid / pp.n_pixels;
-    return rng_sample_key(sc.seed, pixel, pp.sample_first + s_local * pp.sample_stride);
-}
+// Image pixel of the pass's k-th pixel (see PassParams::pixel_map).
+__device__ __forceinline__ uint32_t pass_pixel(const PassParams &pp, uint32_t k) { return pp.pixel_map ? pp.pixel_map[k] : k; }
 
 // ---- nearest hit (linear scan or BVH) -----------------------------------------------------------------
 // The linear scan reads the same primitive in every lane: through a constant-address-space pointer the
@@ -228,9 +228,12 @@ __device__ __forceinline__ bool may_reach_box(V3 lo, V3 hi, V3 o, V3 d) {
 
 // ---- raygen: reference src/tracer.rs:125-142,628-631 -------------------------------------------------------
 // A ray record carries the sample's RNG key (not the sample id), so no level has to redo the pixel/sample split.
+// `sid` = local sample * n_pixels + k is the level-0 record index; the counter RNG is keyed on the IMAGE pixel and the
+// GLOBAL sample index, so which handle renders a pixel-sample, and in which pass, does not change it.
 __device__ __forceinline__ void primary_ray(const DevScene &sc, const PassParams &pp, uint32_t sid, V3 &o, V3 &d, uint32_t &skey) {
-    uint32_t pixel = sid % pp.n_pixels;
-    skey = sample_key_of(sc, pp, sid);
+    const uint32_t k = sid % pp.n_pixels, s_local = sid / pp.n_pixels;
+    const uint32_t pixel = pass_pixel(pp, k);
+    skey = rng_sample_key(sc.seed, pixel, pp.sample_first + s_local * pp.sample_stride);
     camera_ray(sc, pixel % sc.width, pixel / sc.width, skey, o, d);
 }
 
@@ -997,10 +1000,14 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lpre
 }
 
 // ---- resolve: reference src/tracer.rs:634-643 (tone map, gamma, Pixel32::from_unit, add_pixel32) --------------------------
-// One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + pixel) into
+// One thread owns one pixel and folds all `spp` samples of the pass (level-0 records s * n_pixels + k) into
 // its u32 sums: exact integer adds, one plain read-modify-write per pixel and pass, no atomics.
+// `pixels8` (may be null): the display bytes of the pixels this pass touched, from the sums it has just written and
+// `num_samples`, the samples per pixel they hold - Backbuffer::assign_pixel8_unsafe (src/tracer.rs:271-282), which the
+// reference also runs per pixel right after add_pixel32 (:643-644).  The last pass of a frame does this, so presenting
+// costs neither a launch nor a second read of the sums.
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level L1, PassParams pp, uint32_t spp, uint32_t pull,
-                                                  uint32_t *pixels32) {
+                                                  uint32_t *pixels32, uint8_t *pixels8, uint32_t num_samples) {
     // A level overflowed somewhere in this pass: it adds nothing (the host repeats it).  (No launch of the pass is still
     // running when this one starts and it appends nothing itself, so every thread reads the same value.)
     if (*L0.overflow != 0u) return;
@@ -1011,11 +1018,12 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level 
         __syncthreads();
         sc.gamma_table = s_gamma;
     }
-    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < pp.n_pixels; pixel += gridDim.x * BLOCK) {
+    const float n = (float)num_samples;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < pp.n_pixels; k += gridDim.x * BLOCK) {
         uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
 #pragma unroll 2
         for (uint32_t s = 0; s < spp; ++s) {
-            uint32_t i = s * pp.n_pixels + pixel;
+            uint32_t i = s * pp.n_pixels + k;
             float4 c = ld_stream(&L0.coef()[i]);
             const uint32_t kind = node_kind(c);
             V3 value = v3(c.x, c.y, c.z);
@@ -1029,9 +1037,16 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level 
             tonemap_gamma_quantise(sc, value, q);
             acc0 += q[0]; acc1 += q[1]; acc2 += q[2];
         }
-        pixels32[3 * pixel + 0] += acc0;
-        pixels32[3 * pixel + 1] += acc1;
-        pixels32[3 * pixel + 2] += acc2;
+        const uint32_t pixel = pass_pixel(pp, k);
+        const uint32_t s0 = pixels32[3 * pixel + 0] + acc0, s1 = pixels32[3 * pixel + 1] + acc1, s2 = pixels32[3 * pixel + 2] + acc2;
+        pixels32[3 * pixel + 0] = s0;
+        pixels32[3 * pixel + 1] = s1;
+        pixels32[3 * pixel + 2] = s2;
+        if (pixels8 != nullptr) {
+            pixels8[3 * pixel + 0] = (uint8_t)f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s0 / n));
+            pixels8[3 * pixel + 1] = (uint8_t)f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s1 / n));
+            pixels8[3 * pixel + 2] = (uint8_t)f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s2 / n));
+        }
     }
 }
 

@@ -74,8 +74,31 @@ struct PtHandle {
     uint8_t *h_pixels8 = nullptr;  // page-locked host copy handed out by ptgpu_present_pixels8 (sized for the current scene)
     uint32_t *d_ids = nullptr;
     uint64_t num_samples = 0;      // what pixels8 divides by (global count after a multi-GPU combine)
-    uint64_t local_samples = 0;    // samples per pixel this handle accumulated since clear
+    uint64_t local_samples = 0;    // samples per pixel this handle accumulated since clear (ptgpu_render: every pixel of the image)
+    uint64_t tile_samples = 0;     // samples per pixel OF ITS TILES this handle accumulated since clear (ptgpu_render_tiles)
     uint64_t sample_cursor = 0;    // local index of the next sample to render: never reused, also not when a pass was dropped
+
+    // Tile shards (ptgpu_render_tiles): the image pixels of the 32x32 tiles this handle owns among shard_count handles
+    // (ptgpu_tile_shard), tile after tile, row-major inside a tile.  Null when shard_count == 1 (every tile: the identity).
+    uint32_t *d_tile_pixels = nullptr;
+    uint32_t n_tile_pixels = 0;
+
+    // Pipelined presentation (ptgpu_frame): two frames' display bytes on the device and in page-locked host memory.  The
+    // last pass of a frame writes the device copy (k_resolve), the copy stream brings it to the host together with a
+    // snapshot of the overflow flags, and the NEXT call hands it out - so the host never waits for the frame it has just
+    // asked for, and the GPU always has the next frame queued.
+    struct Frame {
+        uint8_t *d_pixels8 = nullptr, *h_pixels8 = nullptr;
+        uint32_t *h_flags = nullptr;     // [FLAG_RING] the overflow flags as they stood when the frame was complete
+        hipEvent_t copied = nullptr;     // recorded on copy_stream behind both copies
+        uint64_t num_samples = 0;        // samples per pixel the image shows
+        uint64_t seq = 0;                // 1, 2, ... since the scene was uploaded or cleared
+        uint64_t last_order = 0;         // `order` of the frame's last pass: the flag snapshot is final for every pass up to it
+        bool in_flight = false;          // enqueued and not yet handed out
+    };
+    Frame frames[2];
+    hipStream_t copy_stream = nullptr;
+    uint64_t frames_begun = 0;
 
     // queues: one set per pass in flight
     int n_levels = 0;              // max_depth + 1
@@ -95,8 +118,11 @@ struct PtHandle {
     bool fixed_capacity = false;       // PtConfig.branch_capacity given: no re-allocation, overflow is an error
     uint32_t *d_flags = nullptr;       // [FLAG_RING] one flag per pass in flight
     uint64_t flag_cursor = 0;
-    struct Pending { uint32_t slot, spp, first; };
+    // A pass as launched: `spp` samples per pixel with global sample indices first, first + stride, ...; tiles: only the
+    // pixels of this handle's tiles.  `frame`: the ptgpu_frame it belongs to (0: none).
+    struct Pending { uint32_t slot, spp, first, stride; bool tiles; uint64_t order; };
     std::vector<Pending> pending;
+    uint64_t launched = 0;             // passes launched so far: `order` of the next one
     bool fused = true;
     bool ahead = false;           // trace-ahead pipeline: a kernel shades its records and traces their children (fuse_trace_shade 3)
     bool lds_scene = false;       // primitive/material tables fit the shade kernel's LDS copy
@@ -193,8 +219,14 @@ void free_levels(PtHandle *h) {
 void free_scene(PtHandle *h) {
     dev_free(h->d_sph); dev_free(h->d_pln); dev_free(h->d_mat); dev_free(h->d_lights); dev_free(h->d_sky); dev_free(h->d_gamma);
     dev_free(h->d_bvh_nodes); dev_free(h->d_bvh_always); dev_free(h->d_prim_rows); dev_free(h->d_shade_rows);
-    dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids);
+    dev_free(h->d_pixels32); dev_free(h->d_pixels8); dev_free(h->d_ids); dev_free(h->d_tile_pixels);
+    h->n_tile_pixels = 0;
     if (h->h_pixels8) { (void)hipHostFree(h->h_pixels8); h->h_pixels8 = nullptr; }
+    for (PtHandle::Frame &f : h->frames) {
+        dev_free(f.d_pixels8);
+        if (f.h_pixels8) { (void)hipHostFree(f.h_pixels8); f.h_pixels8 = nullptr; }
+        f.in_flight = false;
+    }
     free_levels(h);
     dev_free(h->d_ctr); dev_free(h->d_flags);
     h->pending.clear();
@@ -442,18 +474,35 @@ static int grid_tiles(uint64_t level0_records) {
 }
 #define GRID_TILES grid_tiles(S)
 
-// Enqueues one pipeline pass on `pipe`: `spp` samples per pixel starting at local sample index `local_first`.  `flag` is the
-// pass's overflow word (device memory): cleared at the start of the pass, set by an append that finds a level full.
-int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_first, uint32_t *flag) {
-    const uint32_t P = h->sc.width * h->sc.height;
+// What one pipeline pass renders: `spp` samples per pixel with the global sample indices first, first + stride, ... -
+// for every pixel of the image, or (tiles) for the pixels of this handle's tiles.  pixels8 != null: the pass also leaves
+// the display bytes of its pixels there, computed from the sums it has just written and `shown` samples per pixel.
+struct PassSpec {
+    uint32_t spp, first, stride;
+    bool tiles;
+    uint8_t *pixels8;
+    uint32_t shown;
+};
+// The pass ptgpu_render cuts out of the handle's own sample shard: local sample indices local_first ...
+PassSpec own_shard_pass(const PtHandle *h, uint32_t spp, uint32_t local_first) {
+    return PassSpec{spp, h->cfg.shard_index + local_first * h->cfg.shard_count, h->cfg.shard_count, false, nullptr, 0u};
+}
+
+// Enqueues one pipeline pass on `pipe`.  `flag` is the pass's overflow word (device memory): cleared at the start of the
+// pass, set by an append that finds a level full.
+int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, const PassSpec &ps, uint32_t *flag) {
+    const uint32_t spp = ps.spp;
+    const bool mapped = ps.tiles && h->d_tile_pixels != nullptr;
+    const uint32_t P = mapped ? h->n_tile_pixels : h->sc.width * h->sc.height;
     const DevScene &sc = pipe.sc;
     std::vector<Level> &levels = pipe.levels;
     const uint32_t S = P * spp;
     const int D = h->cfg.max_depth;
     PassParams pp;
     pp.n_pixels = P;
-    pp.sample_stride = h->cfg.shard_count;
-    pp.sample_first = h->cfg.shard_index + local_first * h->cfg.shard_count;
+    pp.sample_stride = ps.stride;
+    pp.sample_first = ps.first;
+    pp.pixel_map = mapped ? h->d_tile_pixels : nullptr;
     hipStream_t st = pipe.stream;
     const uint32_t flat_grid = (uint32_t)std::min<uint64_t>(8192, (S + BLOCK - 1) / BLOCK);
     const size_t lds = h->lds_bytes;
@@ -542,7 +591,8 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
     if (other && other->resolved_pending) HIPCHK(h, hipStreamWaitEvent(st, other->resolved, 0));
     {
         Span s(h, PT_KERNEL_RESOLVE, st);
-        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], levels[1], pp, spp, D >= 2 ? 1u : 0u, h->d_pixels32);
+        k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], levels[1], pp, spp, D >= 2 ? 1u : 0u, h->d_pixels32,
+                                                                                                 ps.pixels8, ps.shown);
     }
     k_account<<<1, 64, 0, st>>>(pipe.d_counts, pipe.d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
     HIPCHK(h, hipGetLastError());
@@ -553,34 +603,37 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, uint32_t spp, uint32_t local_
 
 // The next pass of the handle's own queues: round-robin over the pipes, its overflow flag a slot of the ring that is
 // remembered (with the samples it stands for) until the host has looked at it.
-int launch_pass(PtHandle *h, uint32_t spp, uint32_t local_first) {
+int launch_pass(PtHandle *h, const PassSpec &ps) {
     Pipe &pipe = h->pipes[h->passes % h->n_pipes];
     Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;  // the pass before this one
     const uint32_t slot = (uint32_t)(h->flag_cursor++ % FLAG_RING);
-    h->pending.push_back({slot, spp, local_first});
-    int rc = run_pass(h, pipe, other, spp, local_first, h->d_flags + slot);
+    h->pending.push_back({slot, ps.spp, ps.first, ps.stride, ps.tiles, h->launched++});
+    int rc = run_pass(h, pipe, other, ps, h->d_flags + slot);
     if (rc) return rc;
     ++h->passes;
     return PT_OK;
 }
+Pipe &last_pipe(PtHandle *h) { return h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes]; }   // (of the pass launched last)
 
 int sync_pipes(PtHandle *h) {
     for (Pipe &p : h->pipes) {
         if (p.stream) HIPCHK(h, hipStreamSynchronize(p.stream));
         p.resolved_pending = false;
     }
+    if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));   // (frames on their way to the host read what later calls may change)
     return PT_OK;
 }
 
 // Looks at the overflow flags of the passes launched since the last look (all streams idle).  Voided passes are
 // repeated: with the levels re-allocated for twice the branching each time round, which ends at the latest when a
 // level can hold 2^level records per sample.  With a fixed PtConfig.branch_capacity an overflow is an error instead.
-struct Range { uint32_t first, spp; };
+struct Range { uint32_t first, spp, stride; bool tiles; };
 void drop_voided(PtHandle *h, const std::vector<Range> &todo) {
-    uint64_t lost = 0;
-    for (const Range &r : todo) lost += r.spp;
-    h->local_samples -= std::min(h->local_samples, lost);
-    h->num_samples -= std::min(h->num_samples, lost);
+    for (const Range &r : todo) {
+        uint64_t &mine = r.tiles ? h->tile_samples : h->local_samples;
+        mine -= std::min<uint64_t>(mine, r.spp);
+        h->num_samples -= std::min<uint64_t>(h->num_samples, r.spp);
+    }
 }
 
 int resolve_pending(PtHandle *h) {
@@ -592,7 +645,7 @@ int resolve_pending(PtHandle *h) {
             HIPCHK(h, hipMemcpy(flags.data(), h->d_flags, FLAG_RING * 4, hipMemcpyDeviceToHost));
             bool any = false;
             for (const auto &p : h->pending)
-                if (flags[p.slot]) { todo.push_back({p.first, p.spp}); any = true; }
+                if (flags[p.slot]) { todo.push_back({p.first, p.spp, p.stride, p.tiles}); any = true; }
             h->pending.clear();
             if (any) {
                 if (h->fixed_capacity || h->growth >= (1u << 30)) {
@@ -621,15 +674,143 @@ int resolve_pending(PtHandle *h) {
         while (!todo.empty() && h->pending.size() + PT_MAX_PIPES < FLAG_RING) {
             Range &r = todo.back();
             const uint32_t spp = std::min(h->batch, r.spp);  // (the pass size may have shrunk with the new level sizes)
-            int rc = launch_pass(h, spp, r.first);
+            int rc = launch_pass(h, PassSpec{spp, r.first, r.stride, r.tiles, nullptr, 0u});
             if (rc) { drop_voided(h, todo); return rc; }
-            r.first += spp;
+            r.first += spp * r.stride;
             r.spp -= spp;
             if (r.spp == 0) todo.pop_back();
         }
         int rc = sync_pipes(h);
         if (rc) return rc;
     }
+}
+
+// Enqueues n samples per pixel as passes of at most h->batch.  tiles == false: the next n samples of the handle's own
+// sample shard, for every pixel (ptgpu_render).  tiles == true: the global sample indices first .. first + n - 1 for the
+// pixels of the handle's tiles.  pixels8 != null: the last pass leaves the display bytes of its pixels there, for `shown`
+// samples per pixel (0: the handle's own count after this call).  join: order the handle's stream behind every pipe
+// at the end (what ptgpu_stream promises for ptgpu_render; a frame loop must not, or pipe 0's next pass would wait for
+// the other pipes' passes to finish instead of running beside them).
+// strided (with tiles == false): not the handle's own shard but the global sample indices first, first + stride, ... - how
+// a group hands a member its share of a range that does not start where the member's own cursor stands.
+int render_range(PtHandle *h, uint32_t n, bool tiles, uint32_t first, uint8_t *pixels8, uint32_t shown, bool join = true, uint32_t strided = 0u) {
+    if (tiles && h->d_tile_pixels && h->n_tile_pixels == 0) {   // more shards than tiles: nothing to render, the counts advance
+        h->tile_samples += n;
+        h->num_samples += n;
+        return PT_OK;
+    }
+    uint32_t done = 0;
+    while (done < n) {
+        const uint32_t spp = std::min(h->batch, n - done);
+        PassSpec ps = tiles ? PassSpec{spp, first + done, 1u, true, nullptr, 0u}
+                    : strided ? PassSpec{spp, first + done * strided, strided, false, nullptr, 0u}
+                              : own_shard_pass(h, spp, (uint32_t)h->sample_cursor);
+        if (pixels8 && done + spp == n) {
+            ps.pixels8 = pixels8;
+            ps.shown = shown ? shown : (uint32_t)(h->num_samples + spp);
+        }
+        int rc = launch_pass(h, ps);
+        if (rc) return rc;
+        done += spp;
+        if (tiles) h->tile_samples += spp;
+        else { h->local_samples += spp; if (!strided) h->sample_cursor += spp; }
+        h->num_samples += spp;
+        if (h->pending.size() + PT_MAX_PIPES >= FLAG_RING) {  // every flag slot is in use: look at them now
+            if ((rc = sync_pipes(h))) return rc;
+            if ((rc = resolve_pending(h))) return rc;
+        }
+        if (h->cfg.profile_events && h->spans.size() > 4096) {
+            if ((rc = sync_pipes(h))) return rc;
+            if ((rc = drain_spans(h))) return rc;
+        }
+    }
+    // Calls that touch the accumulator (clear, import, upload) finish on the host before they return, so the other pipes
+    // need no edge FROM the handle's stream; successive calls overlap like the passes of one call.
+    if (join)
+        for (int q = 1; q < h->n_pipes; ++q)
+            if (h->pipes[q].resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->pipes[q].resolved, 0));
+    return PT_OK;
+}
+
+// ---- pipelined presentation ------------------------------------------------------------------------------------------
+// Frame k = ++frames_begun lives in frames[k & 1].  Begin: its samples are enqueued, the last pass writing the display
+// bytes into the frame's device buffer.  (The slot was last used by frame k - 2, which the call before this one handed
+// out after waiting for its copy: nothing still reads it.)
+int frame_begin(PtHandle *h, uint32_t n, bool tiles, uint32_t first, uint32_t shown) {
+    PtHandle::Frame &f = h->frames[(h->frames_begun + 1) & 1];
+    const size_t bytes = (size_t)h->sc.width * h->sc.height * 3;
+    if (!f.d_pixels8) {
+        int rc = dev_alloc(h, &f.d_pixels8, bytes);
+        if (rc) return rc;
+        HIPCHK(h, hipMemset(f.d_pixels8, 0, bytes));
+    }
+    if (!f.h_pixels8) HIPCHK(h, hipHostMalloc((void **)&f.h_pixels8, bytes, hipHostMallocDefault));
+    int rc = render_range(h, n, tiles, first, f.d_pixels8, shown, false);
+    if (rc) return rc;
+    ++h->frames_begun;
+    f.seq = h->frames_begun;
+    f.num_samples = shown ? shown : h->num_samples;
+    f.last_order = h->launched;   // (every pass with order < last_order)
+    f.in_flight = true;
+    return PT_OK;
+}
+
+// The frame's way to the host, on the copy stream behind the frame's last pass: display bytes, then the overflow flags
+// (final for every pass launched so far: a pass's resolve step is ordered behind its predecessor's, and a flag is only
+// ever raised before its own pass's resolve step).
+int frame_copy(PtHandle *h, PtHandle::Frame &f, const uint8_t *src = nullptr) {
+    const size_t bytes = (size_t)h->sc.width * h->sc.height * 3;
+    if (h->passes > 0 && last_pipe(h).resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, last_pipe(h).resolved, 0));
+    HIPCHK(h, hipMemcpyAsync(f.h_pixels8, src ? src : f.d_pixels8, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync(f.h_flags, h->d_flags, FLAG_RING * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipEventRecord(f.copied, h->copy_stream));
+    return PT_OK;
+}
+
+// Waits for frame `f` and retires the passes its flag snapshot covers.  *voided: one of them overflowed a queue level -
+// its samples are missing from the sums and from every image computed since; the caller recovers (frame_take).
+int frame_wait(PtHandle *h, PtHandle::Frame &f, bool *voided) {
+    HIPCHK(h, hipEventSynchronize(f.copied));
+    f.in_flight = false;
+    *voided = false;
+    size_t keep = 0;
+    for (size_t k = 0; k < h->pending.size(); ++k) {
+        const PtHandle::Pending &p = h->pending[k];
+        if (p.order < f.last_order) {
+            if (f.h_flags[p.slot]) { *voided = true; return PT_OK; }   // (pending stays whole: resolve_pending goes through it)
+            continue;
+        }
+        h->pending[keep++] = p;
+    }
+    h->pending.resize(keep);
+    return PT_OK;
+}
+
+// The frame a call hands out: the one before the newest (so the host never waits for what it has just enqueued), or
+// the newest itself when it is the first since upload / clear, or when nothing new was asked for (a flush).
+// *out == nullptr: there is no such frame (nothing was rendered through frames yet), or a pass overflowed a queue level
+// and its samples are missing from the frames in flight - everything has then been synchronised and the voided passes
+// rendered again with larger levels, the frame pipeline starts afresh, and the caller presents the sums as they stand.
+void frames_reset(PtHandle *h) {
+    for (PtHandle::Frame &f : h->frames) f.in_flight = false;
+    h->frames_begun = 0;
+}
+int frame_take(PtHandle *h, bool began_one, PtHandle::Frame **out) {
+    *out = nullptr;
+    if (h->frames_begun == 0) return PT_OK;
+    const uint64_t target = (began_one && h->frames_begun >= 2) ? h->frames_begun - 1 : h->frames_begun;
+    PtHandle::Frame &f = h->frames[target & 1];
+    bool voided = false;
+    int rc = frame_wait(h, f, &voided);
+    if (rc) return rc;
+    if (voided) {
+        if ((rc = sync_pipes(h))) return rc;
+        if ((rc = resolve_pending(h))) return rc;
+        frames_reset(h);
+        return PT_OK;
+    }
+    *out = &f;
+    return PT_OK;
 }
 
 // ---- ptgpu_render without any allocation -------------------------------------------------------------------------
@@ -711,6 +892,11 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
     for (int q = 1; q < PT_MAX_PIPES; ++q) ok = ok && hipStreamCreateWithFlags(&h->pipes[q].stream, hipStreamNonBlocking) == hipSuccess;
     for (Pipe &p : h->pipes) ok = ok && hipEventCreateWithFlags(&p.resolved, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->static_pipe.resolved, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (PtHandle::Frame &f : h->frames) {
+        ok = ok && hipEventCreateWithFlags(&f.copied, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&f.h_flags, FLAG_RING * 4, hipHostMallocDefault) == hipSuccess;
+    }
     if (!ok) { ptgpu_destroy(h); return PT_ERR_HIP; }
     // this device's copy of the static scratch array (device cfg->device is current)
     if (cfg->device < PT_MAX_DEVICES) {
@@ -739,8 +925,14 @@ void ptgpu_destroy(PtHandle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (Pipe &p : h->pipes) if (p.stream) (void)hipStreamSynchronize(p.stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     free_scene(h);
     drain_level_pool(h);
+    for (PtHandle::Frame &f : h->frames) {
+        if (f.copied) (void)hipEventDestroy(f.copied);
+        if (f.h_flags) (void)hipHostFree(f.h_flags);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (Pipe &p : h->pipes) if (p.resolved) (void)hipEventDestroy(p.resolved);
     if (h->static_pipe.resolved) (void)hipEventDestroy(h->static_pipe.resolved);
     for (int q = 1; q < PT_MAX_PIPES; ++q) if (h->pipes[q].stream) (void)hipStreamDestroy(h->pipes[q].stream);
@@ -763,6 +955,7 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     HIPCHK(h, hipSetDevice(h->device));
     // every pipe, not only the handle's stream: a render call that failed midway never joined the others into it
     for (Pipe &p : h->pipes) if (p.stream) HIPCHK(h, hipStreamSynchronize(p.stream));
+    if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     free_scene(h);
 
     std::vector<float4> sph, pln, mat, lights;
@@ -899,6 +1092,20 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     if ((rc = dev_alloc(h, &h->d_pixels32, P * 3))) return rc;
     if ((rc = dev_alloc(h, &h->d_pixels8, P * 3))) return rc;
     if ((rc = dev_alloc(h, &h->d_ids, P))) return rc;
+    if (h->cfg.shard_count > 1) {   // the pixels of this handle's tiles, for ptgpu_render_tiles
+        std::vector<uint32_t> mine;
+        const uint32_t tiles_x = (s->width + PT_TILE - 1) / PT_TILE, tiles_y = (s->height + PT_TILE - 1) / PT_TILE;
+        for (uint32_t ty = 0; ty < tiles_y; ++ty)
+            for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+                if (ptgpu_tile_shard(tx, ty, tiles_x, h->cfg.shard_count) != h->cfg.shard_index) continue;
+                // clipped to the image like the tiles of the CPU pool (the reference never clips, src/window.rs:167-178)
+                for (uint32_t y = ty * PT_TILE; y < std::min(s->height, (ty + 1) * PT_TILE); ++y)
+                    for (uint32_t x = tx * PT_TILE; x < std::min(s->width, (tx + 1) * PT_TILE); ++x) mine.push_back(y * s->width + x);
+            }
+        h->n_tile_pixels = (uint32_t)mine.size();
+        if ((rc = dev_alloc(h, &h->d_tile_pixels, std::max<size_t>(1, mine.size())))) return rc;
+        if (!mine.empty()) HIPCHK(h, hipMemcpy(h->d_tile_pixels, mine.data(), mine.size() * 4, hipMemcpyHostToDevice));
+    }
     if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_flags, (size_t)FLAG_RING))) return rc;
     HIPCHK(h, hipMemset(h->d_flags, 0, FLAG_RING * 4));
@@ -925,12 +1132,17 @@ int ptgpu_clear(PtHandle *h) {
     const size_t P = (size_t)h->sc.width * h->sc.height;
     HIPCHK(h, hipMemsetAsync(h->d_pixels32, 0, P * 3 * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_pixels8, 0, P * 3, h->stream));
+    for (PtHandle::Frame &f : h->frames) {
+        if (f.d_pixels8) HIPCHK(h, hipMemsetAsync(f.d_pixels8, 0, P * 3, h->stream));   // (a tile shard only ever writes its own tiles)
+    }
+    frames_reset(h);
     HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int rc = drain_spans(h);
     if (rc) return rc;
     h->num_samples = 0;
     h->local_samples = 0;
+    h->tile_samples = 0;
     h->sample_cursor = 0;
     std::memset(h->kernel_launches, 0, sizeof h->kernel_launches);
     std::memset(h->kernel_ms, 0, sizeof h->kernel_ms);
@@ -943,29 +1155,47 @@ int ptgpu_render(PtHandle *h, uint32_t n_samples) {
     if (!h) return PT_ERR_INVALID_ARGUMENT;
     if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
     HIPCHK(h, hipSetDevice(h->device));
-    // Calls that touch the accumulator (clear, import, upload) finish on the host before they return, so the second
-    // pipe needs no edge from the handle's stream; successive render calls overlap like the passes of one call.
-    uint32_t done = 0;
-    while (done < n_samples) {
-        uint32_t spp = std::min(h->batch, n_samples - done);
-        int rc = launch_pass(h, spp, (uint32_t)h->sample_cursor);
-        if (rc) return rc;
-        done += spp;
-        h->sample_cursor += spp;
-        h->local_samples += spp;
-        h->num_samples += spp;
-        if (h->pending.size() + PT_MAX_PIPES >= FLAG_RING) {  // every flag slot is in use: look at them now
-            if ((rc = sync_pipes(h))) return rc;
-            if ((rc = resolve_pending(h))) return rc;
-        }
-        if (h->cfg.profile_events && h->spans.size() > 4096) {
-            if ((rc = sync_pipes(h))) return rc;
-            if ((rc = drain_spans(h))) return rc;
-        }
+    return render_range(h, n_samples, false, 0u, nullptr, 0u);
+    PT_API_END(h)
+}
+
+int ptgpu_render_tiles(PtHandle *h, uint64_t first_sample, uint32_t n_samples) {
+    PT_API_BEGIN
+    if (!h) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (first_sample + n_samples > 0xFFFFFFFFull) return fail(h, PT_ERR_INVALID_ARGUMENT, "sample indices are 32-bit");
+    HIPCHK(h, hipSetDevice(h->device));
+    return render_range(h, n_samples, true, (uint32_t)first_sample, nullptr, 0u);
+    PT_API_END(h)
+}
+
+uint32_t ptgpu_tile_shard(uint32_t tile_x, uint32_t tile_y, uint32_t tiles_x, uint32_t n) {
+    if (n <= 1) return 0;
+    // tile_id mod n, with the rows shifted against each other when a row holds a whole number of rounds (else every
+    // shard would own whole columns of tiles)
+    const uint64_t id = (uint64_t)tile_y * tiles_x + tile_x + (tiles_x % n == 0 ? tile_y : 0u);
+    return (uint32_t)(id % n);
+}
+
+int ptgpu_frame(PtHandle *h, uint32_t n_samples, const uint8_t **pixels, uint64_t *num_samples) {
+    PT_API_BEGIN
+    if (!h || !pixels) return PT_ERR_INVALID_ARGUMENT;
+    if (!h->have_scene) return fail(h, PT_ERR_NO_SCENE, "no scene uploaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (n_samples > 0) {
+        if ((rc = frame_begin(h, n_samples, false, 0u, 0u))) return rc;
+        if ((rc = frame_copy(h, h->frames[h->frames_begun & 1]))) return rc;
     }
-    // join: later work on the handle's stream is ordered after both pipes
-    for (int q = 1; q < h->n_pipes; ++q)
-        if (h->pipes[q].resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->pipes[q].resolved, 0));
+    PtHandle::Frame *f = nullptr;
+    if ((rc = frame_take(h, n_samples > 0, &f))) return rc;
+    if (!f) {   // (no frame to hand out: the display bytes of the sums as they stand, the synchronous way)
+        if ((rc = ptgpu_present_pixels8(h, pixels))) return rc;
+        if (num_samples) *num_samples = h->num_samples;
+        return PT_OK;
+    }
+    *pixels = f->h_pixels8;
+    if (num_samples) *num_samples = f->num_samples;
     return PT_OK;
     PT_API_END(h)
 }
@@ -1049,7 +1279,7 @@ int ptgpu_render_noalloc(PtHandle *h, uint32_t n_samples) {
         while (r.count > 0 && n_launched < NOALLOC_FLAGS) {
             const uint32_t k = std::min(spp, r.count);
             uint32_t *flag = (uint32_t *)(h->scratch_ptr + pl.flags_off) + n_launched;
-            int rc = run_pass(h, pipe, nullptr, k, r.first, flag);
+            int rc = run_pass(h, pipe, nullptr, own_shard_pass(h, k, r.first), flag);
             if (rc) {   // (the passes already enqueued in this round still run and add their samples: count them)
                 (void)hipGetLastError();
                 (void)settle();
@@ -1244,7 +1474,8 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
         out->queue_growth = h->has_glass ? h->growth : 1u;
         out->terminal_records = c.terminal;
         for (int l = 0; l < 25; ++l) out->level_records[l] = c.level_records[l];
-        out->samples = h->local_samples * (uint64_t)h->sc.width * h->sc.height;
+        const uint64_t P = (uint64_t)h->sc.width * h->sc.height;
+        out->samples = h->local_samples * P + h->tile_samples * (h->d_tile_pixels ? (uint64_t)h->n_tile_pixels : P);
     }
     out->bvh_nodes = h->bvh_nodes;
     out->bvh_leaf_prims = h->bvh_leaf_prims;

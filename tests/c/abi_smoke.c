@@ -1,8 +1,8 @@
 /* A host written in plain C99 against include/ptgpu.h: what a cgo / Rust-bindgen / ctypes consumer sees.
  * Renders a few samples of a two-primitive scene and prints the accumulator's checksum; the Python test compares it
  * with the same scene rendered through the ctypes binding.  Then the same frames through a one-device PtGroup (the
- * in-library multi-GPU path, RCCL reduction included) in the window loop's pattern - one sample and one present per
- * frame - which must print the same sums. */
+ * in-library multi-GPU path, RCCL exchange included) in the window loop's pattern - ptgpu_group_frame: one sample per
+ * frame, each call handing out the frame before it, a flush at the end - which must print the same sums. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -66,11 +66,13 @@ int main(int argc, char **argv) {
         const uint8_t *gshown = NULL;
         if ((rc = ptgpu_group_create(&cfg, &device, 1, &g)) != PT_OK) { fprintf(stderr, "ptgpu_group_create: %d\n", rc); return 6; }
         if ((rc = ptgpu_group_upload_scene(g, &sc)) != PT_OK) { fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g)); return 7; }
-        for (frame = 0; frame < spp; ++frame) {   /* src/window.rs:127-213: one sample per frame, then present */
-            if ((rc = ptgpu_group_render(g, 1)) != PT_OK || (rc = ptgpu_group_present_pixels8(g, &gshown)) != PT_OK) {
+        for (frame = 0; frame <= spp; ++frame) {   /* src/window.rs:127-213: one sample per frame, shown one frame behind; then a flush */
+            uint64_t showing = 0;
+            if ((rc = ptgpu_group_frame(g, frame < spp ? 1u : 0u, &gshown, &showing)) != PT_OK) {
                 fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g));
                 return 8;
             }
+            if (showing != (frame == 0 ? 1u : frame)) { fprintf(stderr, "frame %u shows %llu samples\n", (unsigned)frame, (unsigned long long)showing); return 8; }
         }
         if ((rc = ptgpu_group_read_pixels32(g, p32, &gn)) != PT_OK) { fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g)); return 9; }
         for (int i = 0; i < 32 * 24 * 3; ++i) { gsum += p32[i]; gmix = (gmix ^ p32[i]) * 1099511628211ull; }

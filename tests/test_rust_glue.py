@@ -149,6 +149,6 @@ def test_patches_apply_to_the_reference(tmp_path):
     window = (work / "src" / "window.rs").read_text()
     code = re.sub(r"//[^\n]*", "", window)
     assert "worker_pool" not in code and "backbuffer" not in code and "worker::" not in code
-    assert "renderer.render_frame(1)" in window and "renderer.present()" in window and window.count("renderer.upload(") == 3
+    assert "renderer.frame(samples_per_frame)" in window and "let raw = shown;" in window and window.count("renderer.upload(") == 3
     assert "pub fn flatten(&self) -> ::ptgpu::PtCamera" in (work / "src" / "tracer.rs").read_text()
     assert "mod ptgpu;" in (work / "src" / "main.rs").read_text() and 'build = "build.rs"' in (work / "Cargo.toml").read_text()
