@@ -141,6 +141,8 @@ typedef struct {
     uint64_t bvh_level_fold;                  /* 1: the 4-wide tree was folded level by level because folding by box area was too deep */
     uint64_t queue_bytes;                     /* the part of device_bytes held by the ray queue levels */
     uint64_t level_records[25];               /* queue records per path-tree level since clear (level 0 = primary rays, level max_depth = terminal light samples) */
+    uint64_t samples_per_pass;                /* samples per pixel one pipeline pass takes at most (PtConfig.samples_per_batch, or what auto chose) */
+    uint64_t passes_in_flight;                /* pipeline passes that can be in flight at once (BVH scenes: one large one, plus two that only take passes of a few samples) */
 } PtStats;
 
 typedef struct PtHandle PtHandle;
@@ -167,16 +169,17 @@ int ptgpu_sync(PtHandle *h);
 /* One iteration of the window loop - the tile fan-out + wait() of a frame AND the hand-over of Backbuffer.pixels8 to
  * glDrawPixels (src/window.rs:166-213) - with the two pipelined: the call enqueues n_samples more samples per pixel
  * (the reference's frame is 1: the literal of src/window.rs:166), whose last pass also writes the display bytes
- * (assign_pixel8_unsafe, src/tracer.rs:271-282, for the sums and the sample count as they stand after this frame), and
- * returns in *pixels the display bytes of the frame BEFORE it - complete by now, or nearly - in page-locked memory the
- * library owns; *num_samples (may be NULL) = the samples per pixel that image shows.  The host draws one frame behind
- * and never waits for the frame it has just asked for, and the GPU always has the next frame queued: a loop of
+ * (assign_pixel8_unsafe, src/tracer.rs:271-282, for the sums and the sample count as they stand after this frame) and
+ * which then travel to page-locked host memory on a stream of their own, and returns in *pixels the NEWEST FRAME THAT
+ * HAS ARRIVED there - this call's own when the GPU is ahead of the host, else an earlier one, at the oldest the frame
+ * two before this call's, which is waited for; *num_samples (may be NULL) = the samples per pixel that image shows.
+ * The host never waits for the frame it has just asked for and the GPU always has frames queued: a loop of
  * ptgpu_render(h, 1) + ptgpu_present_pixels8 leaves the GPU idle while the host waits, copies and draws.
- * Every image handed out is exactly Backbuffer.pixels8 after that many samples - the bytes ptgpu_read_pixels8 gives
- * after the same number of ptgpu_render samples.  The first call after ptgpu_upload_scene / ptgpu_clear has no frame
- * before it and waits for its own; n_samples == 0 renders nothing and returns the newest frame (a flush: the last
- * image of a loop).  *pixels stays valid until the next call but one.  A frame is one pipeline pass when n_samples is at
- * most the pass size (PtConfig.samples_per_batch; 0 = auto). */
+ * Every image handed out is exactly Backbuffer.pixels8 after *num_samples samples - the bytes ptgpu_read_pixels8 gives
+ * after that many ptgpu_render samples.  The first call after ptgpu_upload_scene / ptgpu_clear waits for its own frame;
+ * n_samples == 0 renders nothing and waits for the newest frame (a flush: the last image of a loop).  *pixels stays
+ * valid until the next call.  A frame is one pipeline pass when n_samples is at most the pass size
+ * (PtConfig.samples_per_batch; 0 = auto). */
 int ptgpu_frame(PtHandle *h, uint32_t n_samples, const uint8_t **pixels, uint64_t *num_samples);
 
 /* Tile shards - the other way to split the path over several handles (the first: PtConfig.shard_index / shard_count
@@ -287,8 +290,8 @@ int ptgpu_group_render(PtGroup *g, uint32_t n_samples);
 /* ptgpu_frame for the group: one iteration of the window loop (src/window.rs:166-213) on every GPU of the node.  The
  * frame's n_samples are split by image tile, each device's last pass writes the display bytes of its own tiles, one RCCL
  * exchange of bytes (ncclReduce of ncclUint8: disjoint tiles, a quarter of the size of the sums) gathers them on the first
- * device, and the call returns the frame BEFORE this one from page-locked memory; no device waits for the host, no
- * device waits for another's sums.  The images are exactly Backbuffer.pixels8 after *num_samples samples.  After a
+ * device, and the call returns the newest frame that has arrived in page-locked host memory (at the oldest the frame two
+ * before this call's, as ptgpu_frame); no device waits for the host, no device waits for another's sums.  The images are exactly Backbuffer.pixels8 after *num_samples samples.  After a
  * ptgpu_group_render that split by sample index (until the next clear) the frames are not pipelined: each call then
  * renders, reduces the sums and returns its own frame. */
 int ptgpu_group_frame(PtGroup *g, uint32_t n_samples, const uint8_t **pixels, uint64_t *num_samples);

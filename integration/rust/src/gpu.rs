@@ -3,7 +3,7 @@
 //!
 //! The reference drives `WorkerPool::process(tile)` x tiles + `wait()` once per frame (src/window.rs:166-196) and
 //! shows `Backbuffer.pixels8` (:205-210).  `GpuRenderer::frame` is those two steps pipelined (the window shows the
-//! frame before the one it has just enqueued); `render_frame` + `present` are the same two steps one after the other.
+//! newest frame that has reached the host, at most two behind the one it has just enqueued); `render_frame` + `present` are the same two steps one after the other.
 #![allow(dead_code)]
 
 use std::ffi::CStr;
@@ -174,8 +174,8 @@ impl GpuRenderer {
 
     /// One iteration of the window loop (src/window.rs:166-213): enqueues `samples` more samples per pixel (the
     /// reference's frame is 1) and returns the display bytes - `Backbuffer.pixels8` as glDrawPixels wants it: RGB8,
-    /// bottom row first - of the frame BEFORE this one, in the library's page-locked memory, valid until the next call
-    /// but one.  With all GPUs of the node each frame is split over them by 32x32 tile.
+    /// bottom row first - of the newest frame that has arrived in the library's page-locked memory (at the oldest the
+    /// frame two before this one), valid until the next call.  With all GPUs of the node each frame is split over them by 32x32 tile.
     pub fn frame(&mut self, samples: u32) -> Result<*const u8, GpuError> {
         let mut shown: *const u8 = ptr::null();
         let rc = unsafe {

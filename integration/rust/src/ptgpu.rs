@@ -171,6 +171,8 @@ pub struct PtStats {
     pub bvh_level_fold: u64,
     pub queue_bytes: u64,
     pub level_records: [u64; 25],
+    pub samples_per_pass: u64,
+    pub passes_in_flight: u64,
 }
 
 pub enum PtHandle {}

@@ -60,7 +60,8 @@ class PtStats(C.Structure):
                 ("bvh_leaf_prims", C.c_uint64), ("bvh_steps", C.c_uint64), ("kernel_launches", C.c_uint64 * PT_KERNEL_COUNT),
                 ("kernel_ms", C.c_double * PT_KERNEL_COUNT), ("device_bytes", C.c_uint64), ("queue_growth", C.c_uint64), ("debug_cycles", C.c_uint64 * 8),
                 ("bvh_depth", C.c_uint64), ("bvh_binary_depth", C.c_uint64), ("bvh_forced_median_splits", C.c_uint64),
-                ("bvh_level_fold", C.c_uint64), ("queue_bytes", C.c_uint64), ("level_records", C.c_uint64 * 25)]
+                ("bvh_level_fold", C.c_uint64), ("queue_bytes", C.c_uint64), ("level_records", C.c_uint64 * 25),
+                ("samples_per_pass", C.c_uint64), ("passes_in_flight", C.c_uint64)]
 
 
 class PtGpuError(RuntimeError):
@@ -255,6 +256,7 @@ def _stats_dict(st: PtStats) -> dict:
         "bvh_depth": st.bvh_depth, "bvh_binary_depth": st.bvh_binary_depth,
         "bvh_forced_median_splits": st.bvh_forced_median_splits, "bvh_level_fold": st.bvh_level_fold,
         "queue_bytes": st.queue_bytes, "level_records": [int(st.level_records[k]) for k in range(25)],
+        "samples_per_pass": int(st.samples_per_pass), "passes_in_flight": int(st.passes_in_flight),
     }
 
 

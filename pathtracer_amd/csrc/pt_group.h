@@ -63,9 +63,9 @@ struct PtGroup {
                                   // complete sums, which is what lets a device compute the display bytes of its tiles alone
     bool shared_device = false;   // test configuration: several members on ONE device (PTGPU_GROUP_SHARED_DEVICE=1), exchanges by
                                   // a kernel on that device instead of RCCL, which refuses two ranks on one GPU
-    // pipelined presentation (ptgpu_group_frame): frame k lives in slot k & 1 here and in every member
+    // pipelined presentation (ptgpu_group_frame): frame k lives in slot k % FRAME_SLOTS here and in every member
     struct Frame { uint8_t *d_img8 = nullptr, *h_img8 = nullptr; uint64_t num_samples = 0; };
-    Frame frames[2];
+    Frame frames[FRAME_SLOTS];
     uint64_t frames_begun = 0;
     uint64_t exchange_bytes = 0;
     double exchange_ms = 0.0;
@@ -459,40 +459,43 @@ int ptgpu_group_frame(PtGroup *g, uint32_t n_samples, const uint8_t **pixels, ui
         if (rc) { g->have_scene = false; g->error += " (ptgpu_group_frame failed part-way: upload the scene again)"; return rc; }
         g->cursor += n_samples;
         g->frames_begun = seq;
-        PtGroup::Frame &gf = g->frames[seq & 1];
+        PtGroup::Frame &gf = g->frames[seq % FRAME_SLOTS];
         gf.num_samples = shown;
         // the one exchange of the frame: the devices' tiles (disjoint, zero elsewhere) summed onto the first device, each
         // member's part behind its own last pass; then the image and every member's overflow flags on their way to the host
-        rc = group_sum_onto_first(g, gf.d_img8, bytes, false, [g, seq](uint32_t k) { return (const void *)g->members[k]->frames[seq & 1].d_pixels8; },
+        rc = group_sum_onto_first(g, gf.d_img8, bytes, false, [g, seq](uint32_t k) { return (const void *)frame_slot(g->members[k], seq).d_pixels8; },
                                   [g](uint32_t k) { PtHandle *h = g->members[k]; return (h->passes > 0 && last_pipe(h).resolved_pending) ? last_pipe(h).resolved : (hipEvent_t) nullptr; });
         if (rc) return rc;
         for (uint32_t k = 0; k < n; ++k) {
             PtHandle *h = g->members[k];
-            PtHandle::Frame &f = h->frames[seq & 1];
             GHIPCHK(g, hipSetDevice(g->devices[k]));
             if (k == 0) GHIPCHK(g, hipMemcpyAsync(gf.h_img8, gf.d_img8, bytes, hipMemcpyDeviceToHost, h->copy_stream));
-            GHIPCHK(g, hipMemcpyAsync(f.h_flags, h->d_flags, FLAG_RING * 4, hipMemcpyDeviceToHost, h->copy_stream));
-            GHIPCHK(g, hipEventRecord(f.copied, h->copy_stream));
+            if ((rc = frame_copy(h, frame_slot(h, seq), true))) return group_fail(g, rc, ptgpu_last_error(h));
         }
     }
     if (g->frames_begun == 0) return present_now();   // (a flush before any frame)
-    // hand out the frame before the newest (the newest when it is the first, or on a flush), once every member's part of
-    // it has arrived and none of its passes overflowed
-    const uint64_t target = (n_samples > 0 && g->frames_begun >= 2) ? g->frames_begun - 1 : g->frames_begun;
+    // hand out the newest frame of which every member's part has arrived - at the oldest the frame two before the newest,
+    // which is waited for -, provided none of its passes overflowed
+    const uint64_t target = frame_choice(g->frames_begun, n_samples > 0, [g, n](uint64_t seq) {
+        for (uint32_t k = 0; k < n; ++k)
+            if (hipEventQuery(frame_slot(g->members[k], seq).copied) != hipSuccess) return false;
+        return true;
+    });
+    (void)hipGetLastError();
     bool voided = false;
     for (uint32_t k = 0; k < n; ++k) {
         PtHandle *h = g->members[k];
         bool v = false;
         GHIPCHK(g, hipSetDevice(g->devices[k]));
-        if ((rc = frame_wait(h, h->frames[target & 1], &v))) return group_fail(g, rc, ptgpu_last_error(h));
+        if ((rc = frame_wait(h, frame_slot(h, target), &v))) return group_fail(g, rc, ptgpu_last_error(h));
         voided |= v;
     }
     if (voided) {
         if ((rc = group_frames_reset(g, true))) return rc;
         return present_now();
     }
-    *pixels = g->frames[target & 1].h_img8;
-    if (num_samples) *num_samples = g->frames[target & 1].num_samples;
+    *pixels = g->frames[target % FRAME_SLOTS].h_img8;
+    if (num_samples) *num_samples = g->frames[target % FRAME_SLOTS].num_samples;
     return PT_OK;
     PT_API_END(nullptr)
 }
@@ -560,6 +563,7 @@ int ptgpu_group_get_stats(PtGroup *g, PtStats *out) {
         out->bvh_binary_depth = s.bvh_binary_depth; out->bvh_forced_median_splits = s.bvh_forced_median_splits;
         out->bvh_level_fold = s.bvh_level_fold;
         out->queue_growth = std::max(out->queue_growth, s.queue_growth);
+        out->samples_per_pass = s.samples_per_pass; out->passes_in_flight = s.passes_in_flight;
     }
     return PT_OK;
     PT_API_END(nullptr)

@@ -1006,8 +1006,15 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lpre
 // `num_samples`, the samples per pixel they hold - Backbuffer::assign_pixel8_unsafe (src/tracer.rs:271-282), which the
 // reference also runs per pixel right after add_pixel32 (:643-644).  The last pass of a frame does this, so presenting
 // costs neither a launch nor a second read of the sums.
+// `flag_snapshot` (with pixels8): block 0 first copies the handle's ring of overflow flags there.  Every pass launched
+// before this one has finished by now and this pass's own flag can no longer change (appends happen before the resolve
+// step), so the copy is final for all of them - and it travels to the host in the same transfer as the display bytes.
+constexpr uint32_t PASS_FLAG_RING = 1024;
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level L1, PassParams pp, uint32_t spp, uint32_t pull,
-                                                  uint32_t *pixels32, uint8_t *pixels8, uint32_t num_samples) {
+                                                  uint32_t *pixels32, uint8_t *pixels8, uint32_t num_samples, const uint32_t *flag_ring,
+                                                  uint32_t *flag_snapshot) {
+    if (flag_snapshot != nullptr && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < PASS_FLAG_RING; i += BLOCK) flag_snapshot[i] = flag_ring[i];
     // A level overflowed somewhere in this pass: it adds nothing (the host repeats it).  (No launch of the pass is still
     // running when this one starts and it appends nothing itself, so every thread reads the same value.)
     if (*L0.overflow != 0u) return;
@@ -1019,10 +1026,13 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level 
         sc.gamma_table = s_gamma;
     }
     const float n = (float)num_samples;
-    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < pp.n_pixels; k += gridDim.x * BLOCK) {
+    // (whole waves walk the pixels, so that the lanes of a wave can hand each other their display bytes below)
+    for (uint32_t first = blockIdx.x * BLOCK + (threadIdx.x & ~63u); first < pp.n_pixels; first += gridDim.x * BLOCK) {
+        const uint32_t k = first + lane_id();
+        const bool valid = k < pp.n_pixels;
         uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
 #pragma unroll 2
-        for (uint32_t s = 0; s < spp; ++s) {
+        for (uint32_t s = 0; valid && s < spp; ++s) {
             uint32_t i = s * pp.n_pixels + k;
             float4 c = ld_stream(&L0.coef()[i]);
             const uint32_t kind = node_kind(c);
@@ -1037,15 +1047,39 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level 
             tonemap_gamma_quantise(sc, value, q);
             acc0 += q[0]; acc1 += q[1]; acc2 += q[2];
         }
-        const uint32_t pixel = pass_pixel(pp, k);
-        const uint32_t s0 = pixels32[3 * pixel + 0] + acc0, s1 = pixels32[3 * pixel + 1] + acc1, s2 = pixels32[3 * pixel + 2] + acc2;
-        pixels32[3 * pixel + 0] = s0;
-        pixels32[3 * pixel + 1] = s1;
-        pixels32[3 * pixel + 2] = s2;
+        const uint32_t pixel = valid ? pass_pixel(pp, k) : 0u;
+        uint32_t s0 = 0, s1 = 0, s2 = 0;
+        if (valid) {
+            s0 = pixels32[3 * pixel + 0] + acc0; s1 = pixels32[3 * pixel + 1] + acc1; s2 = pixels32[3 * pixel + 2] + acc2;
+            pixels32[3 * pixel + 0] = s0;
+            pixels32[3 * pixel + 1] = s1;
+            pixels32[3 * pixel + 2] = s2;
+        }
         if (pixels8 != nullptr) {
-            pixels8[3 * pixel + 0] = (uint8_t)f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s0 / n));
-            pixels8[3 * pixel + 1] = (uint8_t)f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s1 / n));
-            pixels8[3 * pixel + 2] = (uint8_t)f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s2 / n));
+            const uint32_t b0 = f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s0 / n)), b1 = f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s1 / n)),
+                           b2 = f32_as_u8(min_rs(255.0f, sc.iso_factor * (float)s2 / n));
+            // Three bytes per pixel, 96 per half wave: written as 24 whole words by the first 24 lanes of each half when the
+            // half's 32 pixels lie side by side in the image and start on a word (a row of a tile, or 32 pixels of a row of
+            // the image: always, except at a clipped tile's edge and at the end of the image) - byte stores otherwise.
+            const uint32_t half = lane_id() & 32u, j = lane_id() & 31u;
+            const uint32_t pixel_h = (uint32_t)__shfl((int)pixel, (int)half);
+            const bool side_by_side = valid && pixel == pixel_h + j && (pixel_h & 3u) == 0u;
+            const unsigned long long ok = __ballot(side_by_side);
+            const bool words = ((ok >> half) & 0xffffffffull) == 0xffffffffull;
+            const uint32_t mine = b0 | (b1 << 8) | (b2 << 16);
+            // word j of the half holds bytes 4j .. 4j + 3 of its 96: the tail of pixel 4j / 3 and the head of the next
+            const uint32_t p0 = (4u * j) / 3u, r = (4u * j) % 3u;
+            const uint32_t w0 = (uint32_t)__shfl((int)mine, (int)(half + (p0 & 31u))), w1 = (uint32_t)__shfl((int)mine, (int)(half + ((p0 + 1u) & 31u)));
+            if (words) {
+                if (j < 24u) {
+                    const unsigned long long both = ((unsigned long long)w0 >> (8u * r)) | ((unsigned long long)w1 << (8u * (3u - r)));
+                    reinterpret_cast<uint32_t *>(pixels8 + 3 * (size_t)pixel_h)[j] = (uint32_t)both;
+                }
+            } else if (valid) {
+                pixels8[3 * pixel + 0] = (uint8_t)b0;
+                pixels8[3 * pixel + 1] = (uint8_t)b1;
+                pixels8[3 * pixel + 2] = (uint8_t)b2;
+            }
         }
     }
 }

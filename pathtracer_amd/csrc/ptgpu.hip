@@ -37,7 +37,8 @@ constexpr uint32_t NOALLOC_FLAGS = 64;   // overflow flags (= passes) per round 
 // What one pipeline pass owns: its queues, counters, stream and (BVH scenes) traversal spill area.  Passes on
 // different pipes overlap on the GPU; only the accumulation into the pixel sums is ordered between them.
 constexpr int PT_MAX_PIPES = 4;
-constexpr uint32_t FLAG_RING = 1024;
+constexpr uint32_t FLAG_RING = PASS_FLAG_RING;
+constexpr int FRAME_SLOTS = 3;   // frames of ptgpu_frame in flight at most: the newest two and the one handed out
 struct Pipe {
     hipStream_t stream = nullptr;      // pipe 0 uses the handle's stream
     hipEvent_t resolved = nullptr;     // recorded after the pass has added its samples to the accumulator
@@ -45,7 +46,8 @@ struct Pipe {
     std::vector<Level> levels;
     std::vector<std::pair<void *, size_t>> level_allocs;  // (block, bytes) of each queue level
     uint32_t *d_counts = nullptr;      // [(n_levels + 2) * NSHARD * CSTRIDE]: per level, then the shadow-ray row, then the traced row
-    uint32_t *d_shard_caps = nullptr;  // [n_levels] shard capacity of each level (the handle's array: all its pipes are sized alike)
+    uint32_t *d_shard_caps = nullptr;  // [n_levels] shard capacity of each level (this pipe's part of the handle's array)
+    uint32_t batch = 0;                // samples per pixel its levels are sized for
     uint2 *d_bvh_spill = nullptr;
     DevScene sc{};                     // the handle's scene with this pipe's spill area
 };
@@ -83,20 +85,21 @@ struct PtHandle {
     uint32_t *d_tile_pixels = nullptr;
     uint32_t n_tile_pixels = 0;
 
-    // Pipelined presentation (ptgpu_frame): two frames' display bytes on the device and in page-locked host memory.  The
-    // last pass of a frame writes the device copy (k_resolve), the copy stream brings it to the host together with a
-    // snapshot of the overflow flags, and the NEXT call hands it out - so the host never waits for the frame it has just
-    // asked for, and the GPU always has the next frame queued.
+    // Pipelined presentation (ptgpu_frame): the display bytes of up to FRAME_SLOTS frames on the device and in page-locked
+    // host memory, each followed (at flags_offset) by a snapshot of the overflow flags.  The last pass of a frame writes
+    // the device copy (k_resolve), the copy stream brings it to the host in one transfer, and a LATER call hands it out -
+    // so the host never waits for the frame it has just asked for, and the GPU always has the next frames queued.
     struct Frame {
-        uint8_t *d_pixels8 = nullptr, *h_pixels8 = nullptr;
-        uint32_t *h_flags = nullptr;     // [FLAG_RING] the overflow flags as they stood when the frame was complete
-        hipEvent_t copied = nullptr;     // recorded on copy_stream behind both copies
+        uint8_t *d_pixels8 = nullptr, *h_pixels8 = nullptr;   // [flags_offset + FLAG_RING * 4]
+        bool has_flags = false;          // a pass wrote the snapshot (false: the frame needed none - a tile shard without tiles)
+        hipEvent_t copied = nullptr;     // recorded on copy_stream behind the transfer
         uint64_t num_samples = 0;        // samples per pixel the image shows
         uint64_t seq = 0;                // 1, 2, ... since the scene was uploaded or cleared
         uint64_t last_order = 0;         // `order` of the frame's last pass: the flag snapshot is final for every pass up to it
         bool in_flight = false;          // enqueued and not yet handed out
     };
-    Frame frames[2];
+    Frame frames[FRAME_SLOTS];
+    size_t flags_offset = 0;             // of the current image: its display bytes rounded up to 256
     hipStream_t copy_stream = nullptr;
     uint64_t frames_begun = 0;
 
@@ -104,12 +107,13 @@ struct PtHandle {
     int n_levels = 0;              // max_depth + 1
     uint32_t batch = 0;            // samples per pixel per pass
     int n_pipes = 0;
-    uint64_t passes = 0;           // passes launched since the scene was uploaded (pass k runs on pipe k % n_pipes)
+    uint64_t passes = 0;           // passes launched since the scene was uploaded
+    int prev_pipe = 0;             // the pipe of the pass launched last (the next one takes the next pipe that is large enough)
     Pipe pipes[PT_MAX_PIPES];
     unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
     Pipe static_pipe;                      // ptgpu_render_noalloc's pass: queues carved out of scratch_ptr, the handle's stream
     bool no_spans = false;                 // inside ptgpu_render_noalloc: no per-kernel events (creating one allocates)
-    uint32_t *d_shard_caps = nullptr;  // [n_levels]
+    uint32_t *d_shard_caps = nullptr;  // [n_pipes * n_levels]
     Counters *d_ctr = nullptr;
     // Levels of a scene with glass are sized for `growth`-fold branching, not for the worst case 2^depth.  Every pass
     // has an overflow flag; a pass that filled a level adds nothing to the accumulator and is repeated, after the
@@ -212,7 +216,7 @@ void free_levels(PtHandle *h) {
     }
     h->device_bytes -= h->level_bytes;
     h->level_bytes = 0;
-    if (h->d_shard_caps) h->device_bytes -= (uint64_t)h->n_levels * 4;
+    if (h->d_shard_caps) h->device_bytes -= (uint64_t)h->n_levels * 4 * (uint64_t)std::max(1, h->n_pipes);
     dev_free(h->d_shard_caps);
 }
 
@@ -358,71 +362,89 @@ int drain_spans(PtHandle *h) {
     return PT_OK;
 }
 
-__global__ void k_set_counts0(uint32_t *count0, uint32_t n_records, uint32_t shard_cap, uint32_t *overflow) {
+// Start of a pass: every counter row zero (levels, the shadow-ray row, the traced row), the pass's overflow flag down,
+// and level 0 holding records 0 .. n_records - 1 (its shards filled one after the other).  One launch: a pass of one
+// sample per pixel is a handful of short kernels, and a separate fill for the zeroes would be one more of them.
+__global__ void k_set_counts0(uint32_t *counts, uint32_t n_rows, uint32_t n_records, uint32_t shard_cap, uint32_t *overflow) {
     if (threadIdx.x == 0) *overflow = 0u;
-    uint32_t q = threadIdx.x;
-    uint64_t start = (uint64_t)q * shard_cap;
-    uint32_t c = 0;
-    if (start < n_records) c = (uint32_t)std::min<uint64_t>(shard_cap, n_records - start);
-    count0[q * CSTRIDE] = c;
-    if (q == 0) { count0[1] = 0; count0[2] = 0; }  // work counter of the dynamic-fetch trace kernel; its count of records left to k_rescan
+    for (uint32_t i = threadIdx.x; i < n_rows * NSHARD * CSTRIDE; i += blockDim.x) {
+        uint32_t c = 0;
+        if (i < NSHARD * CSTRIDE && (i % CSTRIDE) == 0u) {   // row 0, the counter of shard q (the words beside it: see k_trace_dyn)
+            const uint32_t q = i / CSTRIDE;
+            const uint64_t start = (uint64_t)q * shard_cap;
+            if (start < n_records) c = (uint32_t)std::min<uint64_t>(shard_cap, n_records - start);
+        }
+        counts[i] = c;
+    }
 }
 
 uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) * m); }
 
-// auto.  Small scenes: two passes in flight - the forward kernels are bound by arithmetic and latency, the backward
-// sweep by HBM bandwidth, and one pass's sweep runs under the other's forward kernels (+4-7 % on the sample scene, +5 %
-// on the room; a third pass adds nothing).  BVH scenes: ONE pass of twice the size - a launch of the trace kernel ends
-// with a few rays that walk hundreds of nodes on an otherwise idle GPU, and a longer launch dilutes that tail better
-// than a second pass fills it (1M-rectangle field at 1080p: one pass of 64 spp 7 180 Mrays/s, one of 32 spp 6 800, two
-// of 32 spp 6 670).
-int pipes_wanted(const PtHandle *h) {
+// Pipes (passes in flight) and their sizes, auto.
+// Small scenes: two pipes of equal size - the forward kernels are bound by arithmetic and latency, the backward sweep by
+// HBM bandwidth, and one pass's sweep runs under the other's forward kernels (+4-7 % on the sample scene, +5 % on the
+// room; a third pass adds nothing).
+// BVH scenes: ONE large pipe - a launch of the trace kernel ends with a few rays that walk hundreds of nodes on an
+// otherwise idle GPU, and a longer launch dilutes that tail better than a second pass fills it (1M-rectangle field at
+// 1080p: one pass of 64 spp 7 550 Mrays/s, one of 32 spp 7 140, two of 16 spp 6 890, three of 8 spp 6 410) - plus two SMALL
+// ones that only passes of a few samples use: the window loop's frames of one sample, of which three in flight take
+// 1.22 ms each at 1080p where one in flight takes 2.08 (a launch of 2M rays is nearly all tail).  (Three pipes and the
+// copy stream are four streams, as many as a process gets hardware queues; a fourth pipe would share one, and costs.)
+constexpr uint32_t SMALL_PIPE_SPP = 4;
+int big_pipes_wanted(const PtHandle *h) {
     const uint32_t c = h->cfg.concurrent_passes;
     if (c == 0) return h->sc.bvh_nodes ? 1 : 2;
     return (int)std::min<uint32_t>(c, PT_MAX_PIPES);
 }
+int small_pipes_wanted(const PtHandle *h) { return (h->cfg.concurrent_passes == 0 && h->sc.bvh_nodes) ? 2 : 0; }
 
 int alloc_levels(PtHandle *h) {
     const uint32_t P = h->sc.width * h->sc.height;
     const int D = h->cfg.max_depth;
     h->n_levels = D + 1;
     const uint32_t branch_cap = h->growth;
-    // samples per pixel per pass: about 64M records at level 0 (fewer, larger launches), bounded by a
-    // memory budget (worst-case glass branching multiplies the deeper levels by up to branch_capacity)
+    // Samples per pixel per pass, auto: what a memory budget for the queues of all pipes allows, at most 64 (128 for BVH
+    // scenes) and at most 64M (128M) records at level 0.  Measured at 1080p with the pipes as above (profiles/debug/
+    // frame_loop.py; queue memory, Mrays/s): sample scene 2 x 32 spp 44.5 GiB 31 100, 2 x 16 22.3 GiB 30 810, 2 x 11 15.3 GiB
+    // 30 440, 2 x 8 11.1 GiB 29 950, 2 x 4 5.6 GiB 28 850; room at depth 16 2 x 8 39 GiB 23 930, 2 x 3 14.6 GiB 23 630; the
+    // 1M-rectangle field (BVH) 1 x 64 44.5 GiB 7 550, 1 x 32 22.3 GiB 7 140, 1 x 23 16 GiB 6 770.  Scenes without a BVH lose
+    // 1-3 % from 44 to 15 GiB - every kernel boundary drains the chip once, and two passes in flight cover most of that -
+    // so their budget is 16 GiB; the BVH trace kernel's tail costs 10 % there, so BVH scenes keep 48 GiB.  (Allocating the
+    // queues also takes the runtime time: 0.2 s for 44 GiB at first upload.)
     uint32_t b = h->cfg.samples_per_batch;
-    // (measured on the sample scene at 1080p, one pass in flight: 8M records 24.1, 16M 25.3, 32M 26.3, 64M 27.8 Grays/s -
-    // every kernel boundary drains the chip once; with two passes in flight the steps are 28.4 / 28.7 / 29.0.  BVH
-    // scenes gain more: a launch ends with a few rays that walk hundreds of nodes and longer launches dilute that)
-    const uint64_t target = (h->sc.bvh_nodes ? 128u : 64u) << 20;   // (halved below when two such passes exceed the budget)
+    const uint64_t target = (h->sc.bvh_nodes ? 128u : 64u) << 20;
     if (b == 0) b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(h->sc.bvh_nodes ? 128 : 64, target / std::max<uint32_t>(P, 1)));
     auto factor = [&](int l) -> uint64_t {
         if (!h->has_glass) return 1;  // only Translucent branches (reference src/tracer.rs:511-536)
         return std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), branch_cap);
     };
     const uint64_t rec_bytes = Level::RECORD_BYTES;
-    const uint64_t budget = 52ull << 30;  // of the 288 GB of an MI355X, over all passes in flight (the estimate below counts
-                                          // every level at full size: 49.4 GiB for 128M level-0 records at depth 4, of which
-                                          // 47.5 GiB are allocated)
-    for (;;) {
-        uint64_t total = 0;
-        for (int l = 0; l <= D; ++l) total += (uint64_t)P * b * factor(l) * rec_bytes * 5 / 4 * pipes_wanted(h);
-        if (total <= budget || b == 1 || h->cfg.samples_per_batch != 0) break;
-        b = std::max<uint32_t>(1, b / 2);
+    const int n_big = big_pipes_wanted(h);
+    const uint64_t budget = (h->sc.bvh_nodes ? 48ull : 16ull) << 30;  // (the estimate below counts every level at full size)
+    auto estimate = [&](uint32_t spp) { uint64_t t = 0; for (int l = 0; l <= D; ++l) t += (uint64_t)P * spp * factor(l) * rec_bytes * 5 / 4; return t; };
+    if (h->cfg.samples_per_batch == 0) {
+        while (b > 1 && estimate(b) * n_big > budget) {
+            // (halving first: a power of two when the budget is far away; then down in single steps)
+            b = estimate(b / 2) * n_big > budget ? b / 2 : b - 1;
+        }
     }
     h->batch = b;
-    const uint64_t S = (uint64_t)P * b;
-    std::vector<uint32_t> caps(h->n_levels);
+    const int n_small = b > SMALL_PIPE_SPP ? small_pipes_wanted(h) : 0;
+    h->n_pipes = std::min(PT_MAX_PIPES, n_big + n_small);
+    std::vector<uint32_t> caps((size_t)h->n_pipes * h->n_levels);
     int rc;
-    if ((rc = dev_alloc(h, &h->d_shard_caps, (size_t)h->n_levels))) return rc;
-    h->n_pipes = pipes_wanted(h);
+    if ((rc = dev_alloc(h, &h->d_shard_caps, caps.size()))) return rc;
     h->passes = 0;
+    h->prev_pipe = h->n_pipes - 1;
     for (int q = 0; q < h->n_pipes; ++q) {
         Pipe &pipe = h->pipes[q];
+        pipe.batch = q < n_big ? b : SMALL_PIPE_SPP;
+        const uint64_t S = (uint64_t)P * pipe.batch;
         pipe.levels.resize(h->n_levels);
         if ((rc = dev_alloc(h, &pipe.d_counts, (size_t)(h->n_levels + 2) * NSHARD * CSTRIDE))) return rc;
         HIPCHK(h, hipMemsetAsync(pipe.d_counts, 0, (size_t)(h->n_levels + 2) * NSHARD * CSTRIDE * 4, h->stream));
         pipe.sc = h->sc;
-        pipe.d_shard_caps = h->d_shard_caps;
+        pipe.d_shard_caps = h->d_shard_caps + (size_t)q * h->n_levels;
         if (h->sc.bvh_nodes) {
             if ((rc = dev_alloc(h, &pipe.d_bvh_spill, (size_t)(BVH_STACK - BVH_LDS_ENTRIES) * BVH_TRAV_BLOCKS * BVH_STACK_STRIDE))) return rc;
             pipe.sc.bvh_spill = pipe.d_bvh_spill;
@@ -433,7 +455,7 @@ int alloc_levels(PtHandle *h) {
             uint32_t cap = (l == 0) ? round_up(per, 64) : round_up(per + per / 4 + 128, 64);
             if ((uint64_t)cap * NSHARD >= (1ull << 31))
                 return fail(h, PT_ERR_INVALID_ARGUMENT, "queue level too large for 31-bit record indices; lower samples_per_batch");
-            caps[l] = cap;
+            caps[(size_t)q * h->n_levels + l] = cap;
             size_t n = (size_t)cap * NSHARD;
             Level &L = pipe.levels[l];
             L.shard_cap = cap;
@@ -466,11 +488,15 @@ int alloc_levels(PtHandle *h) {
 
 // Blocks of the tile kernels (grid-stride over wave-tiles).  Measured on the sample scene: at 1080p with 8 spp per pass
 // 2048 blocks (all resident, ~6 tiles per wave) is 7 % slower than 8192 (1-2 tiles per wave, the dispatcher balances
-// uneven tiles); with 16 spp per pass 16384 is another 1 % ahead, while a 1-spp pass of a 1024x1024 image loses 6 %
-// with that many mostly empty blocks.  PTGPU_GRID overrides it (tuning only).
+// uneven tiles); with 32 spp per pass and one pass in flight 16384 is another 1 % ahead (with two passes of 11 spp in
+// flight, the default, it is 2.5 % behind 8192, and anything from 1536 to 8192 is the same), while a 1-spp pass of a
+// 1024x1024 image loses 6 % with that many mostly empty blocks.  A pass of ONE sample per pixel (the window loop's frame: 2M records at 1080p, 32k
+// wave-tiles) runs best with 1280-4096 blocks - every wave then takes several tiles and pays its start-up (scene copy to
+// LDS, shard scan, cold instruction cache) once: frame loop at 1080p 0.279 ms per frame with 8192 blocks, 0.262 with 2048,
+// 0.295 with 512.  PTGPU_GRID overrides it (tuning only).
 static int grid_tiles(uint64_t level0_records) {
     static int g = [] { const char *e = getenv("PTGPU_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-    return g ? g : (level0_records >= (16u << 20) ? 16384 : 8192);
+    return g ? g : (level0_records >= (48u << 20) ? 16384 : level0_records > (4u << 20) ? 8192 : 2048);
 }
 #define GRID_TILES grid_tiles(S)
 
@@ -480,7 +506,7 @@ static int grid_tiles(uint64_t level0_records) {
 struct PassSpec {
     uint32_t spp, first, stride;
     bool tiles;
-    uint8_t *pixels8;
+    uint8_t *pixels8;          // (a frame's buffer: the snapshot of the overflow flags goes behind the bytes, see PtHandle::Frame)
     uint32_t shown;
 };
 // The pass ptgpu_render cuts out of the handle's own sample shard: local sample indices local_first ...
@@ -511,9 +537,8 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, const PassSpec &ps, uint32_t 
     const uint32_t RESCAN_GRID = 512;   // (of the kernels that repeat the few records a traversing kernel left to the linear scan)
     const uint32_t TG = sc.bvh_nodes ? std::min<uint32_t>(BVH_TRAV_BLOCKS, GRID_TILES) : GRID_TILES;
 
-    HIPCHK(h, hipMemsetAsync(pipe.d_counts + NSHARD * CSTRIDE, 0, (size_t)(D + 2) * NSHARD * CSTRIDE * 4, st));  // levels 1..D, shadow row, traced row
     for (Level &L : levels) L.overflow = flag;
-    k_set_counts0<<<1, NSHARD, 0, st>>>(levels[0].count, S, levels[0].shard_cap, flag);
+    k_set_counts0<<<1, 1024, 0, st>>>(pipe.d_counts, (uint32_t)(D + 3), S, levels[0].shard_cap, flag);   // levels 0..D, shadow row, traced row
     if (!h->fused && !h->ahead && !bvh) {
         Span s(h, PT_KERNEL_RAYGEN, st);
         k_raygen<<<flat_grid, BLOCK, 0, st>>>(sc, levels[0], pp, S);
@@ -592,28 +617,38 @@ int run_pass(PtHandle *h, Pipe &pipe, Pipe *other, const PassSpec &ps, uint32_t 
     {
         Span s(h, PT_KERNEL_RESOLVE, st);
         k_resolve<<<(uint32_t)std::min<uint64_t>(8192, (P + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(sc, levels[0], levels[1], pp, spp, D >= 2 ? 1u : 0u, h->d_pixels32,
-                                                                                                 ps.pixels8, ps.shown);
+                                                                                                 ps.pixels8, ps.shown, h->d_flags,
+                                                                                                 ps.pixels8 ? reinterpret_cast<uint32_t *>(ps.pixels8 + h->flags_offset) : nullptr);
     }
-    k_account<<<1, 64, 0, st>>>(pipe.d_counts, pipe.d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
-    HIPCHK(h, hipGetLastError());
+    // (the event stands for "this pass has added its samples": what the next pass's resolve step and a frame's copy wait
+    // for; the bookkeeping kernel behind it only feeds the statistics, which are read after a full synchronisation)
     HIPCHK(h, hipEventRecord(pipe.resolved, st));
     pipe.resolved_pending = true;
+    k_account<<<1, 64, 0, st>>>(pipe.d_counts, pipe.d_shard_caps, h->n_levels, h->ahead ? 1 : 0, flag, h->d_ctr);
+    HIPCHK(h, hipGetLastError());
     return PT_OK;
 }
 
 // The next pass of the handle's own queues: round-robin over the pipes, its overflow flag a slot of the ring that is
 // remembered (with the samples it stands for) until the host has looked at it.
 int launch_pass(PtHandle *h, const PassSpec &ps) {
-    Pipe &pipe = h->pipes[h->passes % h->n_pipes];
-    Pipe *other = h->n_pipes > 1 ? &h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes] : nullptr;  // the pass before this one
+    // round-robin over the pipes whose levels hold a pass of this size (a BVH scene's small pipes take frames only)
+    int q = h->prev_pipe;
+    for (int t = 1; t <= h->n_pipes; ++t) {
+        const int c = (h->prev_pipe + t) % h->n_pipes;
+        if (h->pipes[c].batch >= ps.spp) { q = c; break; }
+    }
+    Pipe &pipe = h->pipes[q];
+    Pipe *other = (h->passes > 0 && q != h->prev_pipe) ? &h->pipes[h->prev_pipe] : nullptr;  // the pass before this one
     const uint32_t slot = (uint32_t)(h->flag_cursor++ % FLAG_RING);
     h->pending.push_back({slot, ps.spp, ps.first, ps.stride, ps.tiles, h->launched++});
     int rc = run_pass(h, pipe, other, ps, h->d_flags + slot);
     if (rc) return rc;
     ++h->passes;
+    h->prev_pipe = q;
     return PT_OK;
 }
-Pipe &last_pipe(PtHandle *h) { return h->pipes[(h->passes + h->n_pipes - 1) % h->n_pipes]; }   // (of the pass launched last)
+Pipe &last_pipe(PtHandle *h) { return h->pipes[h->prev_pipe]; }   // (of the pass launched last)
 
 int sync_pipes(PtHandle *h) {
     for (Pipe &p : h->pipes) {
@@ -733,36 +768,44 @@ int render_range(PtHandle *h, uint32_t n, bool tiles, uint32_t first, uint8_t *p
 }
 
 // ---- pipelined presentation ------------------------------------------------------------------------------------------
-// Frame k = ++frames_begun lives in frames[k & 1].  Begin: its samples are enqueued, the last pass writing the display
-// bytes into the frame's device buffer.  (The slot was last used by frame k - 2, which the call before this one handed
-// out after waiting for its copy: nothing still reads it.)
+// Frame k = ++frames_begun lives in slot k % FRAME_SLOTS.  Begin: its samples are enqueued, the last pass writing the
+// display bytes and the flag snapshot into the frame's device buffer.  (The slot was last used by frame k - FRAME_SLOTS,
+// whose transfer an earlier call has waited for - frame_take never lets more than FRAME_SLOTS - 1 frames go unawaited -
+// and which the caller may hold only until this call.)
+PtHandle::Frame &frame_slot(PtHandle *h, uint64_t seq) { return h->frames[seq % FRAME_SLOTS]; }
 int frame_begin(PtHandle *h, uint32_t n, bool tiles, uint32_t first, uint32_t shown) {
-    PtHandle::Frame &f = h->frames[(h->frames_begun + 1) & 1];
+    PtHandle::Frame &f = frame_slot(h, h->frames_begun + 1);
     const size_t bytes = (size_t)h->sc.width * h->sc.height * 3;
+    h->flags_offset = (bytes + 255) & ~(size_t)255;
+    const size_t total = h->flags_offset + FLAG_RING * 4;
     if (!f.d_pixels8) {
-        int rc = dev_alloc(h, &f.d_pixels8, bytes);
+        int rc = dev_alloc(h, &f.d_pixels8, total);
         if (rc) return rc;
-        HIPCHK(h, hipMemset(f.d_pixels8, 0, bytes));
+        HIPCHK(h, hipMemset(f.d_pixels8, 0, total));
     }
-    if (!f.h_pixels8) HIPCHK(h, hipHostMalloc((void **)&f.h_pixels8, bytes, hipHostMallocDefault));
+    if (!f.h_pixels8) HIPCHK(h, hipHostMalloc((void **)&f.h_pixels8, total, hipHostMallocDefault));
+    const uint64_t before = h->launched;
     int rc = render_range(h, n, tiles, first, f.d_pixels8, shown, false);
     if (rc) return rc;
     ++h->frames_begun;
     f.seq = h->frames_begun;
     f.num_samples = shown ? shown : h->num_samples;
-    f.last_order = h->launched;   // (every pass with order < last_order)
+    f.last_order = h->launched;   // (the snapshot is final for every pass with order < last_order)
+    f.has_flags = h->launched != before;
     f.in_flight = true;
     return PT_OK;
 }
 
-// The frame's way to the host, on the copy stream behind the frame's last pass: display bytes, then the overflow flags
-// (final for every pass launched so far: a pass's resolve step is ordered behind its predecessor's, and a flag is only
-// ever raised before its own pass's resolve step).
-int frame_copy(PtHandle *h, PtHandle::Frame &f, const uint8_t *src = nullptr) {
-    const size_t bytes = (size_t)h->sc.width * h->sc.height * 3;
+// The frame's way to the host, on the copy stream behind the frame's last pass: display bytes and flag snapshot in one
+// transfer (`image_only`: the caller moves the bytes itself - a group, which gathers its members' tiles first).
+int frame_copy(PtHandle *h, PtHandle::Frame &f, bool image_only = false) {
     if (h->passes > 0 && last_pipe(h).resolved_pending) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, last_pipe(h).resolved, 0));
-    HIPCHK(h, hipMemcpyAsync(f.h_pixels8, src ? src : f.d_pixels8, bytes, hipMemcpyDeviceToHost, h->copy_stream));
-    HIPCHK(h, hipMemcpyAsync(f.h_flags, h->d_flags, FLAG_RING * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    if (image_only) {
+        if (f.has_flags)
+            HIPCHK(h, hipMemcpyAsync(f.h_pixels8 + h->flags_offset, f.d_pixels8 + h->flags_offset, FLAG_RING * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(f.h_pixels8, f.d_pixels8, h->flags_offset + FLAG_RING * 4, hipMemcpyDeviceToHost, h->copy_stream));
+    }
     HIPCHK(h, hipEventRecord(f.copied, h->copy_stream));
     return PT_OK;
 }
@@ -773,11 +816,13 @@ int frame_wait(PtHandle *h, PtHandle::Frame &f, bool *voided) {
     HIPCHK(h, hipEventSynchronize(f.copied));
     f.in_flight = false;
     *voided = false;
+    if (!f.has_flags) return PT_OK;
+    const uint32_t *flags = reinterpret_cast<const uint32_t *>(f.h_pixels8 + h->flags_offset);
     size_t keep = 0;
     for (size_t k = 0; k < h->pending.size(); ++k) {
         const PtHandle::Pending &p = h->pending[k];
         if (p.order < f.last_order) {
-            if (f.h_flags[p.slot]) { *voided = true; return PT_OK; }   // (pending stays whole: resolve_pending goes through it)
+            if (flags[p.slot]) { *voided = true; return PT_OK; }   // (pending stays whole: resolve_pending goes through it)
             continue;
         }
         h->pending[keep++] = p;
@@ -786,20 +831,32 @@ int frame_wait(PtHandle *h, PtHandle::Frame &f, bool *voided) {
     return PT_OK;
 }
 
-// The frame a call hands out: the one before the newest (so the host never waits for what it has just enqueued), or
-// the newest itself when it is the first since upload / clear, or when nothing new was asked for (a flush).
-// *out == nullptr: there is no such frame (nothing was rendered through frames yet), or a pass overflowed a queue level
-// and its samples are missing from the frames in flight - everything has then been synchronised and the voided passes
-// rendered again with larger levels, the frame pipeline starts afresh, and the caller presents the sums as they stand.
 void frames_reset(PtHandle *h) {
     for (PtHandle::Frame &f : h->frames) f.in_flight = false;
     h->frames_begun = 0;
 }
+// Which frame a call hands out: the newest whose transfer has arrived, but never one older than the frame two before
+// the newest - that one is waited for, which is also what keeps the host from running further ahead of the GPU.  A
+// call that began no frame (a flush) waits for the newest.  0: no frame has been begun since upload / clear.
+template <class Arrived>
+uint64_t frame_choice(uint64_t frames_begun, bool began_one, Arrived arrived) {
+    if (frames_begun == 0) return 0;
+    if (!began_one) return frames_begun;
+    const uint64_t oldest = frames_begun > (uint64_t)(FRAME_SLOTS - 1) ? frames_begun - (FRAME_SLOTS - 1) : 1;
+    for (uint64_t k = frames_begun; k > oldest; --k)
+        if (arrived(k)) return k;
+    return oldest;
+}
+// *out == nullptr: there is no frame to hand out (nothing was rendered through frames yet), or a pass overflowed a queue
+// level and its samples are missing from the frames in flight - everything has then been synchronised and the voided
+// passes rendered again with larger levels, the frame pipeline starts afresh, and the caller presents the sums as they
+// stand.
 int frame_take(PtHandle *h, bool began_one, PtHandle::Frame **out) {
     *out = nullptr;
-    if (h->frames_begun == 0) return PT_OK;
-    const uint64_t target = (began_one && h->frames_begun >= 2) ? h->frames_begun - 1 : h->frames_begun;
-    PtHandle::Frame &f = h->frames[target & 1];
+    const uint64_t target = frame_choice(h->frames_begun, began_one, [h](uint64_t k) { return hipEventQuery(frame_slot(h, k).copied) == hipSuccess; });
+    if (target == 0) return PT_OK;
+    (void)hipGetLastError();   // (hipErrorNotReady of the queries above is no error)
+    PtHandle::Frame &f = frame_slot(h, target);
     bool voided = false;
     int rc = frame_wait(h, f, &voided);
     if (rc) return rc;
@@ -895,7 +952,6 @@ int ptgpu_create(const PtConfig *cfg, PtHandle **out) {
     ok = ok && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (PtHandle::Frame &f : h->frames) {
         ok = ok && hipEventCreateWithFlags(&f.copied, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipHostMalloc((void **)&f.h_flags, FLAG_RING * 4, hipHostMallocDefault) == hipSuccess;
     }
     if (!ok) { ptgpu_destroy(h); return PT_ERR_HIP; }
     // this device's copy of the static scratch array (device cfg->device is current)
@@ -930,7 +986,6 @@ void ptgpu_destroy(PtHandle *h) {
     drain_level_pool(h);
     for (PtHandle::Frame &f : h->frames) {
         if (f.copied) (void)hipEventDestroy(f.copied);
-        if (f.h_flags) (void)hipHostFree(f.h_flags);
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (Pipe &p : h->pipes) if (p.resolved) (void)hipEventDestroy(p.resolved);
@@ -1185,7 +1240,7 @@ int ptgpu_frame(PtHandle *h, uint32_t n_samples, const uint8_t **pixels, uint64_
     int rc;
     if (n_samples > 0) {
         if ((rc = frame_begin(h, n_samples, false, 0u, 0u))) return rc;
-        if ((rc = frame_copy(h, h->frames[h->frames_begun & 1]))) return rc;
+        if ((rc = frame_copy(h, frame_slot(h, h->frames_begun)))) return rc;
     }
     PtHandle::Frame *f = nullptr;
     if ((rc = frame_take(h, n_samples > 0, &f))) return rc;
@@ -1484,6 +1539,8 @@ int ptgpu_get_stats(PtHandle *h, PtStats *out) {
     out->bvh_forced_median_splits = h->bvh_forced_median_splits;
     out->bvh_level_fold = h->bvh_level_fold;
     out->queue_bytes = h->level_bytes;
+    out->samples_per_pass = h->batch;
+    out->passes_in_flight = (uint64_t)h->n_pipes;
     for (int k = 0; k < PT_KERNEL_COUNT; ++k) { out->kernel_launches[k] = h->kernel_launches[k]; out->kernel_ms[k] = h->kernel_ms[k]; }
     out->device_bytes = h->device_bytes;
     return PT_OK;

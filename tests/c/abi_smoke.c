@@ -2,7 +2,7 @@
  * Renders a few samples of a two-primitive scene and prints the accumulator's checksum; the Python test compares it
  * with the same scene rendered through the ctypes binding.  Then the same frames through a one-device PtGroup (the
  * in-library multi-GPU path, RCCL exchange included) in the window loop's pattern - ptgpu_group_frame: one sample per
- * frame, each call handing out the frame before it, a flush at the end - which must print the same sums. */
+ * frame, each call handing out the newest frame that has arrived, a flush at the end - which must print the same sums. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -72,7 +72,8 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g));
                 return 8;
             }
-            if (showing != (frame == 0 ? 1u : frame)) { fprintf(stderr, "frame %u shows %llu samples\n", (unsigned)frame, (unsigned long long)showing); return 8; }
+            /* the newest frame that has arrived: at the oldest the one two before this call's; the flush: the last */
+            if (showing > (frame < spp ? frame + 1u : spp) || showing + 2u < frame + 1u || showing == 0u || (frame == spp && showing != spp)) { fprintf(stderr, "frame %u shows %llu samples\n", (unsigned)frame, (unsigned long long)showing); return 8; }
         }
         if ((rc = ptgpu_group_read_pixels32(g, p32, &gn)) != PT_OK) { fprintf(stderr, "error %d: %s\n", rc, ptgpu_group_last_error(g)); return 9; }
         for (int i = 0; i < 32 * 24 * 3; ++i) { gsum += p32[i]; gmix = (gmix ^ p32[i]) * 1099511628211ull; }

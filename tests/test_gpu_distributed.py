@@ -41,3 +41,29 @@ def test_bench_inproc_group():
     assert d["n_gpus"] == 1 and d["config"]["accumulated_spp"] == 16 and d["value"] > 0 and "PtGroup" in d["config"]["parallelism"]
     assert d["roofline"]["kernel"] == "trace_shade" and 0 < d["roofline"]["frac"] < 1
     assert d["exchange"]["bytes"] == 640 * 360 * 12 and d["exchange"]["ms"] > 0 and d["exchange"]["device_ms"] >= 0
+
+
+@pytest.mark.parametrize("inproc", [False, True])
+def test_bench_strong_scaling_mode(inproc):
+    """bench.py --scaling strong (a fixed total of samples split over the GPUs by sample index; reports seconds to that
+    total and the exchange's share), as one torch.distributed rank and through the library's PtGroup."""
+    args = ["--gpus", "1", "--scaling", "strong", "--width", "320", "--height", "180", "--total-spp", "48", "--steps", "3", "--warmup", "1",
+            "--no-cpu-baseline"]
+    if inproc:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--inproc"] + args
+        env = dict(os.environ)
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, PTGPU_FORCE_COLLECTIVE="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["accumulated_spp"] == 48 and d["value"] > 0
+    assert d["sec_to_total_spp"]["total_spp"] == 48 and 0 < d["sec_to_total_spp"]["of_which_exchange_s"] < d["sec_to_total_spp"]["seconds"]
+    seconds = d["ms_per_step"] * d["steps"] * 1e-3
+    assert abs(d["msamples_per_s"] * 1e6 * seconds / (320 * 180 * 48) - 1.0) < 0.02   # every sample of the total, once
+    assert d["exchange"]["bytes"] == 320 * 180 * 12

@@ -1,6 +1,6 @@
 """The window loop on the GPU (reference src/window.rs:127-229: one sample per pixel per frame, then glDrawPixels of
-Backbuffer.pixels8): ptgpu_frame / ptgpu_group_frame pipeline the two - a call enqueues its frame and hands out the frame
-before - and ptgpu_render_tiles splits a frame over several handles by 32x32 tile.  Every image handed out must be the
+Backbuffer.pixels8): ptgpu_frame / ptgpu_group_frame pipeline the two - a call enqueues its frame and hands out the newest
+frame that has arrived on the host - and ptgpu_render_tiles splits a frame over several handles by 32x32 tile.  Every image handed out must be the
 bytes the synchronous loop (ptgpu_render + ptgpu_read_pixels8) shows after the same number of samples, and the sums of
 tile shards must add up to one handle's, bit for bit."""
 import numpy as np
@@ -34,13 +34,19 @@ def _frame_loop(obj, frames, spp=1):
     return got
 
 
-def _check_sequence(got, want, spp):
-    """Call k hands out frame max(k - 1, 1), the flush the last one."""
-    frames = len(want)
-    expect = [1] + list(range(1, frames)) + [frames]
-    assert [n for _, n in got] == [k * spp for k in expect]
-    for (img, n), k in zip(got, expect):
-        assert np.array_equal(img, want[k - 1][0]), f"frame {k}"
+def _check_sequence(got, want, spp, before=0):
+    """Call k hands out the newest frame that has arrived - its own, or one or two before it (never older: that one is
+    waited for) -, the first call its own, the flush the last; every image is the synchronous loop's after that many
+    samples.  `before`: samples rendered before the first frame."""
+    frames = len(got) - 1
+    shown = [(n - before) // spp for _, n in got]
+    assert all((n - before) % spp == 0 for _, n in got)
+    assert shown[0] == 1 and shown[-1] == frames
+    for k, f in enumerate(shown[:-1], start=1):
+        assert max(1, k - 2) <= f <= k, (k, f)
+    assert shown == sorted(shown)
+    for img, n in got:
+        assert np.array_equal(img, want[n // spp - 1][0]), f"image after {n} samples"
 
 
 @pytest.mark.parametrize("spp,batch", [(1, 0), (3, 2)])
@@ -56,7 +62,7 @@ def test_frame_loop_shows_what_the_synchronous_loop_shows(binding, oracle, spp, 
         assert np.array_equal(gpu.read_pixels8(), want[-1][0])
         # after a clear the loop starts afresh: the first call waits for its own frame again
         gpu.clear()
-        _check_sequence(_frame_loop(gpu, 3, spp), want[:3], spp)
+        _check_sequence(_frame_loop(gpu, 3, spp), want, spp)
     # and the whole thing is the reference's Backbuffer after that many frames
     o32, o8, _ = oracle.OracleScene(sc).render(oracle.options(), 7 * spp)
     assert np.array_equal(want[-1][1], o32) and np.array_equal(want[-1][0], o8)
@@ -70,14 +76,14 @@ def test_frames_mixed_with_render_and_reads(binding):
         img, n = gpu.frame(0)                       # a flush before anything was rendered: the empty backbuffer
         assert n == 0 and not img.any()
         gpu.render(2)                               # plain samples first: the frames count them
-        img, n = gpu.frame(1)
+        img, n = gpu.frame(1)                       # the first frame: waited for
         assert n == 3 and np.array_equal(img, want[2][0])
         assert np.array_equal(gpu.read_pixels8(), want[2][0])     # a synchronous read in the middle
-        img, n = gpu.frame(1)                       # hands out the frame before it
-        assert n == 3 and np.array_equal(img, want[2][0])
+        img, n = gpu.frame(1)                       # its own frame if that has arrived already, else the one before
+        assert n in (3, 4) and np.array_equal(img, want[n - 1][0])
         gpu.render(4)
         img, n = gpu.frame(1)
-        assert n == 4 and np.array_equal(img, want[3][0])
+        assert n in (3, 4, 9) and np.array_equal(img, want[n - 1][0])
         img, n = gpu.frame(0)
         assert n == 9 and np.array_equal(img, want[8][0])
 
@@ -146,7 +152,7 @@ def test_group_of_one_frame_loop(binding):
         img, n = group.frame(0)
         assert n == 5                                # the newest FRAME is still the fifth
         img, n = group.frame(1)
-        assert n == 5
+        assert n in (5, 9)
         img, n = group.frame(0)
         assert n == 9
 
@@ -160,13 +166,13 @@ def test_group_of_four_on_one_device(binding, monkeypatch):
     with binding.PtGroup(devices=[0, 0, 0, 0]) as group:
         assert group.size == 4
         group.upload_scene(sc)
-        _check_sequence(_frame_loop(group, 6), want[:6], 1)
+        _check_sequence(_frame_loop(group, 6), want, 1)
         group.render(2)                              # fewer samples than members: by tile
         p32, n = group.read_pixels32()
         assert n == 8 and np.array_equal(p32, want[7][1])
         assert np.array_equal(group.read_pixels8(), want[7][0])
-        img, n = group.frame(1)                      # still only tile shards: pipelined (the frame before = the sixth)
-        assert n == 6
+        img, n = group.frame(1)                      # still only tile shards: pipelined (its own frame, or the sixth)
+        assert n in (6, 9) and np.array_equal(img, want[n - 1][0])
         img, n = group.frame(0)
         assert n == 9 and np.array_equal(img, want[8][0])
         group.render(7)                              # by sample index: 7 samples over 4 members
@@ -177,4 +183,4 @@ def test_group_of_four_on_one_device(binding, monkeypatch):
         st = group.stats()
         assert st["samples"] == 17 * 160 * 100
         group.clear()
-        _check_sequence(_frame_loop(group, 3), want[:3], 1)
+        _check_sequence(_frame_loop(group, 3), want, 1)
