@@ -319,7 +319,8 @@ void ptgpu_plane_normals(PtPlane *planes, uint64_t n);   /* fills planes[i].norm
 
 /* Device-side evaluation of one deterministic math function over n arguments (test hook for the
  * sin/cos/pow/exp/acos/atan2 replacements the kernels use): fn 0 sin, 1 cos, 2 pow, 3 exp, 4 acos, 5 atan2; and for the
- * basic operations that compile to instruction sequences: 6 sqrt(a), 7 a / b, 8 random32 of a's bit pattern. */
+ * basic operations that compile to instruction sequences: 6 sqrt(a), 7 a / b, 8 random32 of a's bit pattern; 9, 10, 11: the
+ * x, y, z component of normalize((a, b, a * 0.37 + b)) as the kernels evaluate it. */
 int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n);
 /* Device self-test of the gamma quantiser's lookup table (the resolve kernel's fast path for
  * Pixel32::from_unit(gamma_correction(x)), src/tracer.rs:609-616 + src/common.rs:78-82): compares it with the direct

@@ -1166,6 +1166,10 @@ __global__ void k_eval_math(int fn, const float *a, const float *b, float *out, 
         case 6: r = sqrt_ieee(x); break;     // the two basic operations the compiler expands into instruction sequences
         case 7: r = x / y; break;
         case 8: r = (float)f2u(x) / 4294967296.0f; break;   // random32 of the argument's bit pattern (common.rs:38-41)
+        // normalize as the kernels evaluate it (three divisions that may share one refined reciprocal): a component each
+        case 9: r = normalize(v3(x, y, x * 0.37f + y)).x; break;
+        case 10: r = normalize(v3(x, y, x * 0.37f + y)).y; break;
+        case 11: r = normalize(v3(x, y, x * 0.37f + y)).z; break;
         default: r = det::atan2f_(x, y); break;
         }
         out[i] = r;

@@ -53,7 +53,34 @@ PT_HD float sqrt_ieee(float x) {
     return __builtin_sqrtf(x);
 }
 PT_HD float length(V3 a) { return sqrt_ieee(dot(a, a)); }
-PT_HD V3 normalize(V3 a) { return a / length(a); }
+// normalize = three correctly rounded divisions by the same length.  On the device the compiler expands each into eleven
+// instructions: both operands scaled when their exponents call for it (v_div_scale), the hardware reciprocal of the
+// denominator refined once, the quotient refined twice, the last step scaled back (v_div_fmas), special cases patched
+// (v_div_fixup).  When NO scaling applies - every component at least 2^-60 in magnitude (no square underflows, so the
+// length is at least about 2^-60 too), the length at most 2^20: the reciprocal is normal, every quotient is normal, no
+// residual underflows - v_div_scale returns its operands unchanged, v_div_fmas is a plain fused multiply-add and
+// v_div_fixup returns its argument, so the three divisions differ only in their numerators: the reciprocal and its
+// refinement are computed ONCE and each component takes the remaining five operations, the same operations on the same
+// operands as the compiler's expansion, hence the same bits (18 instructions and 3 for the test instead of 33).  A wave
+// with a lane outside those conditions (a zero or vanishing component: a ray along an axis; a length beyond 2^20; NaN,
+// which fails the comparison of the length; infinity) takes the divisions as written.
+PT_HD V3 normalize(V3 a) {
+    const float len = length(a);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_NO_SHARED_RCP)
+    const float least = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    const bool plain = (least >= 0x1p-60f) & (len <= 0x1p20f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) == 0ull, 1)) {
+        float r = __builtin_amdgcn_rcpf(len);
+        r = __builtin_fmaf(__builtin_fmaf(-len, r, 1.0f), r, r);
+        V3 q = v3(a.x * r, a.y * r, a.z * r);
+        for (int round = 0; round < 2; ++round)
+            q = v3(__builtin_fmaf(__builtin_fmaf(-len, q.x, a.x), r, q.x), __builtin_fmaf(__builtin_fmaf(-len, q.y, a.y), r, q.y),
+                   __builtin_fmaf(__builtin_fmaf(-len, q.z, a.z), r, q.z));
+        return q;
+    }
+#endif
+    return a / len;
+}
 
 // Rust f32::max / f32::min: the non-NaN operand wins; for equal operands the second is returned.
 PT_HD float max_rs(float a, float b) { if (b != b) return a; if (a != a) return b; return a > b ? a : b; }

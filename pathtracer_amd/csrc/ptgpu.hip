@@ -1690,7 +1690,7 @@ int ptgpu_selftest_gamma(PtHandle *h, uint64_t *mismatches) {
 
 int ptgpu_eval_math(PtHandle *h, int32_t fn, const float *a, const float *b, float *out, uint64_t n) {
     PT_API_BEGIN
-    if (!h || !a || !out || fn < 0 || fn > 8) return PT_ERR_INVALID_ARGUMENT;
+    if (!h || !a || !out || fn < 0 || fn > 11) return PT_ERR_INVALID_ARGUMENT;
     if (n == 0) return PT_OK;
     HIPCHK(h, hipSetDevice(h->device));
     float *da = nullptr, *db = nullptr, *dout = nullptr;

@@ -482,3 +482,41 @@ def test_basic_operations_match_the_host(binding, oracle):
             got = gpu.eval_math(6, x.view(np.float32), None)
             ref = oracle.math_eval(oracle.MATH_DET, 6, x.view(np.float32), None)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_normalize_with_a_shared_reciprocal_matches_three_divisions(binding):
+    """normalize is three correctly rounded divisions by the same length; waves whose components are all of ordinary size
+    compute the refined reciprocal once (pt_math.h).  Against numpy's IEEE float32 arithmetic, bit for bit: vectors of
+    ordinary size (whole waves on the shared path), vectors with tiny, zero, huge, infinite and NaN components (the
+    divisions as written), and blocks that mix the two."""
+    rng = np.random.RandomState(21)
+    n = 1 << 21
+
+    def reference(x, y):
+        with np.errstate(all="ignore"):
+            z = (x * np.float32(0.37) + y).astype(np.float32)
+            length = np.sqrt(((x * x + y * y) + z * z).astype(np.float32)).astype(np.float32)
+            return [(c / length).astype(np.float32) for c in (x, y, z)]
+
+    ordinary = lambda: (rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-12, 12, n)).astype(np.float32)
+    bits = lambda: rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1e-45, -1e-39, 1e-31, 3e38, -3e38, np.inf, -np.inf, np.nan, 1.0, -2.5], dtype=np.float32)
+    cases = [(ordinary(), ordinary()), (bits(), bits())]
+    x, y = ordinary(), ordinary()
+    x[::193] = special[rng.randint(0, len(special), len(x[::193]))]
+    y[::389] = special[rng.randint(0, len(special), len(y[::389]))]
+    cases.append((x, y))
+    x, y = ordinary(), ordinary()                                        # zeros of both signs stay on the shared path
+    x[::3] = np.where(rng.randint(0, 2, len(x[::3])) == 1, np.float32(0.0), np.float32(-0.0))
+    y[::7] = np.where(rng.randint(0, 2, len(y[::7])) == 1, np.float32(0.0), np.float32(-0.0))
+    cases.append((x, y))
+    e = rng.randint(1, 255, n).astype(np.uint32) << 23                   # every exponent, components of like magnitude
+    cases.append(((e | rng.randint(0, 1 << 23, n).astype(np.uint32)).view(np.float32),
+                  (e | rng.randint(0, 1 << 23, n).astype(np.uint32) | np.uint32(0x80000000)).view(np.float32)))
+    with binding.PtGpu() as gpu:
+        for x, y in cases:
+            want = reference(x, y)
+            for fn, w in zip((9, 10, 11), want):
+                got = gpu.eval_math(fn, x, y)
+                same = (got.view(np.uint32) == w.view(np.uint32)) | (np.isnan(got) & np.isnan(w))
+                assert same.all(), (fn, int((~same).sum()), x[~same][:4], y[~same][:4], got[~same][:4], w[~same][:4])
