@@ -498,6 +498,32 @@ __device__ __forceinline__ V3 child_radiance(const Level &L, const Level &Lup, u
     return node_value(kind, v3(k.x, k.y, k.z), k.w, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z));
 }
 
+// The same, in three steps that a caller can interleave over several records: the sweep kernels are bound by the latency
+// of these dependent fetches (record -> child's coefficients -> the child's own children), not by bandwidth, and a wave
+// that walks a few records' chains side by side keeps that many more requests in flight.
+//   child_fetch_begin: the child's coefficients (or the record's own val slot) are requested;
+//   child_fetch_next:  what the coefficients ask for - the child's val slots - is requested;
+//   child_fetch_value: the child's radiance.
+// `on` false: nothing is requested, the value is zero.  The arithmetic is child_radiance's.
+struct ChildFetch { float4 k, a, b; bool up; };
+__device__ __forceinline__ void child_fetch_begin(ChildFetch &f, const Level &L, const Level &Lup, uint32_t i, uint32_t c, bool on) {
+    f.k = f.a = f.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    f.up = on && c != NO_CHILD;
+    if (on) f.k = f.up ? ld_stream(&Lup.coef()[c]) : ld_stream(&L.val0()[i]);
+}
+__device__ __forceinline__ void child_fetch_next(ChildFetch &f, const Level &Lup, uint32_t c) {
+    if (!f.up) return;
+    const uint32_t kind = node_kind(f.k);
+    if (kind != NK_LEAF) f.a = ld_stream(&Lup.val0()[c]);
+    if (kind == NK_GLASS) f.b = ld_stream(&Lup.val1()[c]);
+}
+__device__ __forceinline__ V3 child_fetch_value(const ChildFetch &f) {
+    if (!f.up) return v3(f.k.x, f.k.y, f.k.z);
+    const uint32_t kind = node_kind(f.k);
+    if (kind == NK_LEAF) return v3(f.k.x, f.k.y, f.k.z);
+    return node_value(kind, v3(f.k.x, f.k.y, f.k.z), f.k.w, v3(f.a.x, f.a.y, f.a.z), v3(f.b.x, f.b.y, f.b.z));
+}
+
 // ---- shade: reference src/tracer.rs:494-583 ----------------------------------------------------------------------
 // One record of level `level`: material switch, node coefficients, children appended to Lnext (level + 1).
 // At level >= 1 a leaf stores its radiance straight into its parent's val slot; at level 0 it keeps it in its own
@@ -977,25 +1003,61 @@ __global__ __launch_bounds__(BLOCK, BVH ? 6 : 1) void k_terminal(DevScene sc, Le
 // ---- backward sweep: the inner nodes of an even level l >= 2 hand their radiance to their parents -----------------
 // `pull`: level l + 1 is a traced level, so the children's radiance is taken from their records there (see
 // remember_children); otherwise (l is the last traced level) it is in the val slots, put there by k_terminal.
+// Wave-tiles whose records a wave walks side by side.  Measured at 1080p (k_gather alone, ms per 16 steps, one pass in
+// flight / whole job with the default two, Mrays/s): sample scene 1 tile 199 / 31 570, 2: 199 / 31 530, 4 (56 registers):
+// 206 / 31 790, 6: 240 / 30 400, 8 (174 registers): 290 / 29 660; closed room 1: 415 / 24 450, 4: 418 / 24 060.  Its
+// scattered 16-byte reads and writes keep HBM at 4 TB/s of actual traffic whatever a wave has in flight.
+#ifndef PT_GATHER_TILES
+#define PT_GATHER_TILES 1
+#endif
+constexpr int GATHER_TILES = PT_GATHER_TILES;
 __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lprev, uint32_t pull) {
     if (pass_voided(L)) return;
     TileMap m = tile_map(L);
-    for (uint32_t w = wave_global(); w < m.total; w += waves_in_grid()) {
-        uint32_t i;
-        if (!tile_record(m, L, w, i)) continue;
-        // On the last traced level most records are leaves (nodes whose terminal samples were all black): there the one
-        // word that says so is read first; elsewhere leaves are rare and everything is requested at once.
-        if (pull == 0u && ld_stream(&L.hitprim()[i]) == LEAF_DONE) continue;
-        float4 c = ld_stream(&L.coef()[i]);
-        if (pull != 0u && ld_stream(&L.hitprim()[i]) == LEAF_DONE) continue;
-        const uint32_t kind = node_kind(c);
-        V3 a = child_radiance(L, Lup, i, 0, pull != 0u);
-        V3 b = v3(0.f, 0.f, 0.f);
-        if (kind == NK_GLASS) b = child_radiance(L, Lup, i, 1, pull != 0u);
-        V3 value = node_value(kind, v3(c.x, c.y, c.z), c.w, a, b);
-        uint32_t par = ld_stream(&L.parent()[i]);
-        float4 v = make_float4(value.x, value.y, value.z, 0.0f);
-        if (par & 1u) st_stream(&Lprev.val1()[par >> 1], v); else st_stream(&Lprev.val0()[par >> 1], v);
+    const uint32_t stride = waves_in_grid();
+    for (uint32_t w = wave_global(); w < m.total; w += GATHER_TILES * stride) {
+        uint32_t i[GATHER_TILES], hp[GATHER_TILES], par[GATHER_TILES];
+        float4 c[GATHER_TILES];
+        bool on[GATHER_TILES];
+        ChildFetch f[GATHER_TILES];
+        // The record's own words (a leaf - LEAF_DONE - handed its radiance down when it was shaded).  On the last traced
+        // level most records are leaves (nodes whose terminal samples were all black): there the one word that says so is
+        // read first; elsewhere leaves are rare and everything is requested at once.
+#pragma unroll
+        for (int u = 0; u < GATHER_TILES; ++u) {
+            const uint32_t wu = w + (uint32_t)u * stride;
+            on[u] = wu < m.total && tile_record(m, L, wu, i[u]);
+            hp[u] = LEAF_DONE; par[u] = 0u;
+            c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on[u]) hp[u] = ld_stream(&L.hitprim()[i[u]]);
+        }
+        if (pull != 0u) {
+#pragma unroll
+            for (int u = 0; u < GATHER_TILES; ++u)
+                if (on[u]) { c[u] = ld_stream(&L.coef()[i[u]]); par[u] = ld_stream(&L.parent()[i[u]]); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < GATHER_TILES; ++u)
+                if (on[u] && hp[u] != LEAF_DONE) { c[u] = ld_stream(&L.coef()[i[u]]); par[u] = ld_stream(&L.parent()[i[u]]); }
+        }
+#pragma unroll
+        for (int u = 0; u < GATHER_TILES; ++u) {
+            on[u] = on[u] && hp[u] != LEAF_DONE;
+            child_fetch_begin(f[u], L, Lup, i[u], pull != 0u ? hp[u] : NO_CHILD, on[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GATHER_TILES; ++u) child_fetch_next(f[u], Lup, hp[u]);
+#pragma unroll
+        for (int u = 0; u < GATHER_TILES; ++u) {
+            if (!on[u]) continue;
+            const uint32_t kind = node_kind(c[u]);
+            V3 a = child_fetch_value(f[u]);
+            V3 b = v3(0.f, 0.f, 0.f);
+            if (kind == NK_GLASS) b = child_radiance(L, Lup, i[u], 1, pull != 0u);
+            V3 value = node_value(kind, v3(c[u].x, c[u].y, c[u].z), c[u].w, a, b);
+            float4 v = make_float4(value.x, value.y, value.z, 0.0f);
+            if (par[u] & 1u) st_stream(&Lprev.val1()[par[u] >> 1], v); else st_stream(&Lprev.val0()[par[u] >> 1], v);
+        }
     }
 }
 
@@ -1010,6 +1072,13 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Level L, Level Lup, Level Lpre
 // before this one has finished by now and this pass's own flag can no longer change (appends happen before the resolve
 // step), so the copy is final for all of them - and it travels to the host in the same transfer as the display bytes.
 constexpr uint32_t PASS_FLAG_RING = 1024;
+// Samples of a pixel whose fetch chains a wave walks side by side (ChildFetch).  Measured at 1080p on the sample scene
+// (k_resolve alone, ms per 16 steps of 22 spp): a plain loop over the samples 175; 2 samples (78 registers with the
+// display bytes' code) 160; 3: 170; 4 (113 registers, half the waves) 188.
+#ifndef PT_RESOLVE_SAMPLES
+#define PT_RESOLVE_SAMPLES 2
+#endif
+constexpr int RESOLVE_SAMPLES = PT_RESOLVE_SAMPLES;
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level L1, PassParams pp, uint32_t spp, uint32_t pull,
                                                   uint32_t *pixels32, uint8_t *pixels8, uint32_t num_samples, const uint32_t *flag_ring,
                                                   uint32_t *flag_snapshot) {
@@ -1031,21 +1100,42 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevScene sc, Level L0, Level 
         const uint32_t k = first + lane_id();
         const bool valid = k < pp.n_pixels;
         uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
-#pragma unroll 2
-        for (uint32_t s = 0; valid && s < spp; ++s) {
-            uint32_t i = s * pp.n_pixels + k;
-            float4 c = ld_stream(&L0.coef()[i]);
-            const uint32_t kind = node_kind(c);
-            V3 value = v3(c.x, c.y, c.z);
-            if (kind != NK_LEAF) {
-                V3 a = child_radiance(L0, L1, i, 0, pull != 0u);
-                V3 b = v3(0.f, 0.f, 0.f);
-                if (kind == NK_GLASS) b = child_radiance(L0, L1, i, 1, pull != 0u);
-                value = node_value(kind, value, c.w, a, b);
+        // RESOLVE_SAMPLES samples' fetch chains side by side (see ChildFetch)
+        for (uint32_t sb = 0; sb < spp; sb += RESOLVE_SAMPLES) {
+            uint32_t i[RESOLVE_SAMPLES], ch[RESOLVE_SAMPLES];
+            float4 c[RESOLVE_SAMPLES];
+            bool on[RESOLVE_SAMPLES];
+            ChildFetch f[RESOLVE_SAMPLES];
+#pragma unroll
+            for (int u = 0; u < RESOLVE_SAMPLES; ++u) {
+                on[u] = valid && sb + (uint32_t)u < spp;
+                i[u] = (sb + (uint32_t)u) * pp.n_pixels + k;
+                c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                ch[u] = NO_CHILD;
+                if (on[u]) {
+                    c[u] = ld_stream(&L0.coef()[i[u]]);
+                    if (pull != 0u) ch[u] = ld_stream(&L0.hitprim()[i[u]]);   // (a leaf's is not used: four bytes against a round trip)
+                }
             }
-            uint32_t q[3];
-            tonemap_gamma_quantise(sc, value, q);
-            acc0 += q[0]; acc1 += q[1]; acc2 += q[2];
+#pragma unroll
+            for (int u = 0; u < RESOLVE_SAMPLES; ++u) child_fetch_begin(f[u], L0, L1, i[u], ch[u], on[u] && node_kind(c[u]) != NK_LEAF);
+#pragma unroll
+            for (int u = 0; u < RESOLVE_SAMPLES; ++u) child_fetch_next(f[u], L1, ch[u]);
+#pragma unroll
+            for (int u = 0; u < RESOLVE_SAMPLES; ++u) {
+                if (!on[u]) continue;
+                const uint32_t kind = node_kind(c[u]);
+                V3 value = v3(c[u].x, c[u].y, c[u].z);
+                if (kind != NK_LEAF) {
+                    V3 a = child_fetch_value(f[u]);
+                    V3 b = v3(0.f, 0.f, 0.f);
+                    if (kind == NK_GLASS) b = child_radiance(L0, L1, i[u], 1, pull != 0u);
+                    value = node_value(kind, value, c[u].w, a, b);
+                }
+                uint32_t q[3];
+                tonemap_gamma_quantise(sc, value, q);
+                acc0 += q[0]; acc1 += q[1]; acc2 += q[2];
+            }
         }
         const uint32_t pixel = valid ? pass_pixel(pp, k) : 0u;
         uint32_t s0 = 0, s1 = 0, s2 = 0;

@@ -781,7 +781,10 @@ int frame_begin(PtHandle *h, uint32_t n, bool tiles, uint32_t first, uint32_t sh
     if (!f.d_pixels8) {
         int rc = dev_alloc(h, &f.d_pixels8, total);
         if (rc) return rc;
+        // (hipMemset of device memory may return before it has run, on the null stream, which the handle's non-blocking
+        // streams do not wait for: without the synchronisation it can land on top of the frame's display bytes)
         HIPCHK(h, hipMemset(f.d_pixels8, 0, total));
+        HIPCHK(h, hipStreamSynchronize(nullptr));
     }
     if (!f.h_pixels8) HIPCHK(h, hipHostMalloc((void **)&f.h_pixels8, total, hipHostMallocDefault));
     const uint64_t before = h->launched;
@@ -1164,6 +1167,7 @@ int ptgpu_upload_scene(PtHandle *h, const PtSceneDesc *s) {
     if ((rc = dev_alloc(h, &h->d_ctr, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_flags, (size_t)FLAG_RING))) return rc;
     HIPCHK(h, hipMemset(h->d_flags, 0, FLAG_RING * 4));
+    HIPCHK(h, hipStreamSynchronize(nullptr));   // (see frame_begin: the passes' streams do not wait for the null stream)
     h->fixed_capacity = h->cfg.branch_capacity != 0;
     // Levels start at one record per sample and level (plus the 25 % slack of every shard): in the reference's scene 0.57 -
     // 0.71 records per sample reach levels 1-3, glass included.  Scenes that branch more overflow once and grow.
