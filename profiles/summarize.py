@@ -35,14 +35,13 @@ def klass(name):
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
-    for f in glob.glob(f"{out}/{tag}_{sub}/*/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            c = klass(r["Kernel_Name"])
-            if c is None:
-                continue
-            agg[c][r["Counter_Name"]] += float(r["Counter_Value"])
-            launches[c][r["Counter_Name"]].add(r["Dispatch_Id"])
+for f in glob.glob(f"{out}/{tag}_pmc_*/*/*counter_collection.csv"):   # (every counter pass taken under this tag)
+    for r in csv.DictReader(open(f)):
+        c = klass(r["Kernel_Name"])
+        if c is None:
+            continue
+        agg[c][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[c][r["Counter_Name"]].add(r["Dispatch_Id"])
 res, traffic = {}, {}
 for c, v in agg.items():
     res[c] = {}
