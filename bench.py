@@ -200,9 +200,17 @@ def main() -> None:
     else:
         import torch
         import torch.distributed as dist
+        if os.environ.get("PTGPU_BENCH_ONE_DEVICE") == "1":
+            # test configuration (one GPU at hand): every rank renders on device 0; RCCL refuses two ranks on one device, so
+            # the exchange then goes over gloo - everything else is the code an N-GPU run executes
+            local_rank = 0
         if world > 1 or os.environ.get("PTGPU_FORCE_COLLECTIVE"):
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            backend = os.environ.get("PTGPU_BENCH_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
         assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
         n_gpus = world
     use_dist = dist is not None and dist.is_initialized()
@@ -294,8 +302,9 @@ def main() -> None:
     st = gpu.stats()
     rays, samples = float(st["rays"]), float(st["samples"])
     if use_dist and world > 1:
-        agg = torch.tensor([rays, samples], dtype=torch.float64, device=dev)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        red = dev if dist.get_backend() == "nccl" else torch.device("cpu")   # (gloo: the one-device test configuration)
+        agg = torch.tensor([rays, samples], dtype=torch.float64, device=red)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rays, samples, elapsed = float(agg[0].item()), float(agg[1].item()), float(tmax[0].item())
@@ -306,9 +315,12 @@ def main() -> None:
     exchange_device_ms = gpu.exchange_stats()["ms"] if args.inproc else None
     if events_in_timed_region:
         one_pass = {"stats": st, "elapsed": elapsed}
-    elif not args.no_events and n_gpus == 1 and not strong:
+    elif not args.no_events and not strong and rank == 0 and (not args.inproc or n_gpus == 1):
+        # (N > 1: rank 0 alone repeats its own shard's steps - the same launches per pass as at N = 1 - while the other
+        # ranks wait at the closing barrier)
         gpu.close()
-        gpu = binding.PtGpu(device=local_rank, **dict(cfg, concurrent_passes=1, samples_per_batch=st["samples_per_pass"], profile_events=1))
+        gpu = binding.PtGpu(device=local_rank, shard_index=rank, shard_count=world,
+                            **dict(cfg, concurrent_passes=1, samples_per_batch=st["samples_per_pass"], profile_events=1))
         gpu.upload_scene(sc)
         for _ in range(args.warmup):
             gpu.render(args.spp_per_step)

@@ -31,6 +31,31 @@ def test_bench_under_torchrun_with_nccl_collective():
     assert d["exchange"]["bytes"] == 640 * 360 * 12 and d["exchange"]["ms"] > 0
 
 
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, two ranks, RANK / LOCAL_RANK / WORLD_SIZE from
+    the environment) - on the one GPU of this box: both ranks render on device 0 (PTGPU_BENCH_ONE_DEVICE) and, RCCL
+    refusing two ranks on one device, exchange over gloo.  Everything else - shard indices, barriers, the sum and the maximum
+    over the ranks, rank 0's line - is the code of an N-GPU run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PTGPU_BENCH_ONE_DEVICE="1", PTGPU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "640", "--height", "360", "--spp-per-step", "32", "--batch", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["accumulated_spp"] == 2 * 2 * 32      # both ranks' samples in every rank's accumulator
+    assert abs(d["msamples_per_s"] * d["timed_region_s"] - 2 * 2 * 32 * 640 * 360 / 1e6) < 0.05 * 2 * 2 * 32 * 640 * 360 / 1e6
+    assert d["roofline"]["kernel"] == "trace_shade" and 0 < d["roofline"]["frac"] < 1   # rank 0's one-pass leg
+    assert "cpu_baseline" not in d and "frame_loop" not in d  # (N = 1 only)
+    assert d["exchange"]["bytes"] == 640 * 360 * 12
+
+
 def test_bench_inproc_group():
     """bench.py --inproc: the same JSON shape with the GPUs driven from one process through the library's PtGroup."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--inproc", "--steps", "2", "--warmup", "1", "--spp-per-step", "8",
