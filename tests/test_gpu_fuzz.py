@@ -214,15 +214,16 @@ def test_random_call_sequences(binding, seed):
                accel=int(rng.choice([0, 2])))
     with binding.PtGpu(**cfg) as gpu:
         cur, n = None, 0
+        frames = []      # (display bytes handed out by a frame call, samples they show) since the last upload or clear
         for _ in range(30):
-            op = rng.randint(0, 8)
+            op = rng.randint(0, 11)
             if cur is None or op == 0:
                 cur = scenes[rng.randint(0, len(scenes))]
                 gpu.upload_scene(cur)
-                n = 0
+                n, frames = 0, []
             elif op == 1:
                 gpu.clear()
-                n = 0
+                n, frames = 0, []
             elif op <= 4:
                 k = int(rng.randint(1, 6))
                 gpu.render(k)
@@ -232,15 +233,27 @@ def test_random_call_sequences(binding, seed):
                 assert ns == n
             elif op == 6:
                 assert gpu.present_pixels8().shape == (cur.image_settings.height, cur.image_settings.width, 3)
-            else:
+            elif op == 7:
                 gpu.sync()
+            else:    # the window loop's call, between everything else: k samples and the newest frame that has arrived
+                k = int(rng.randint(0, 4))
+                img, shown = gpu.frame(k)
+                n += k
+                assert shown <= n
+                frames.append((img.copy(), shown))
         got, ns = gpu.read_pixels32()
         got8 = gpu.read_pixels8()
     assert ns == n
     with binding.PtGpu(max_depth=cfg["max_depth"]) as fresh:
         fresh.upload_scene(cur)
-        if n:
-            fresh.render(n)
+        done = 0
+        for img, shown in sorted(frames, key=lambda f: f[1]):   # every frame handed out: the display bytes after `shown` samples
+            if shown > done:
+                fresh.render(shown - done)
+                done = shown
+            assert np.array_equal(img, fresh.read_pixels8()), (shown, n)
+        if n > done:
+            fresh.render(n - done)
         want, _ = fresh.read_pixels32()
         want8 = fresh.read_pixels8()
     assert np.array_equal(got, want) and np.array_equal(got8, want8)
