@@ -317,7 +317,7 @@ class PtGroup:
 
     def frame(self, n_samples: int = 1):
         """One iteration of the window loop on all GPUs (ptgpu_group_frame): enqueues n_samples, returns (display bytes of the
-        frame before - a view of page-locked memory valid until the next call but one -, samples per pixel they show)."""
+        newest frame that has arrived - a view of page-locked memory valid until the next call -, samples per pixel they show)."""
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.lib.ptgpu_group_frame(self.g, int(n_samples), C.byref(p), C.byref(n)))
         buf = (C.c_uint8 * (self.height * self.width * 3)).from_address(p.value)
@@ -406,8 +406,8 @@ class PtGpu:
         self._chk(self.lib.ptgpu_render_tiles(self.h, int(first_sample), int(n_samples)))
 
     def frame(self, n_samples: int = 1):
-        """One iteration of the window loop (ptgpu_frame): enqueues n_samples, returns (display bytes of the frame before - a
-        view of page-locked memory valid until the next call but one -, samples per pixel they show)."""
+        """One iteration of the window loop (ptgpu_frame): enqueues n_samples, returns (display bytes of the newest frame that
+        has arrived - a view of page-locked memory valid until the next call -, samples per pixel they show)."""
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.lib.ptgpu_frame(self.h, int(n_samples), C.byref(p), C.byref(n)))
         buf = (C.c_uint8 * (self.height * self.width * 3)).from_address(p.value)
