@@ -323,7 +323,14 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
 #endif
     const unsigned long long lt = (1ull << lane_id()) - 1ull;
     const uint32_t n_chunks = (m.total + DYN_TILES - 1) / DYN_TILES;
-    uint32_t *work = L.count + 1;  // chunk counter: a spare word of the level's first counter line, zeroed per pass
+    // Chunk counters: the level's chunks are cut into eight ranges, each with a counter of its own (a spare word of the
+    // first eight counter lines, zeroed per pass), and a wave starts with the range of the XCD it runs on: the eight L2s are
+    // separate, and waves that walk neighbouring rays through the tree re-read each other's nodes (1M-rectangle field:
+    // trace kernel -1.2 %).  A wave whose range is used up goes on with the next one, so the ranges only say where a wave
+    // starts - whatever the register reads (a partitioned device may report one XCD for all), every chunk is claimed once.
+    uint32_t *work = L.count + 1;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;   // HW_REG_XCC_ID, bits 3:0
+    uint32_t ranges_done = 0;
     uint32_t end = 0, next = 0, rec = 0;
     uint32_t tile_base = 0, tile_cnt = 0;   // lane t < DYN_TILES: first record and record count of tile t of the wave's chunk
     bool exhausted = false, active = false;
@@ -341,10 +348,17 @@ __global__ __launch_bounds__(BLOCK, PT_TRACE_WAVES) void k_trace_dyn(DevScene sc
     uint32_t my_steps = 0;  // 64-byte units (2 per inner node, 1 per leaf primitive) this lane fetched: the kernel's algorithmic traffic
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (idle != 0 && next >= end && !exhausted) {  // chunk used up: claim the next one (one atomic per wave and chunk)
-            uint32_t c = 0;
-            if (lane_id() == 0) c = atomicAdd(work, 1u);
-            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (idle != 0 && next >= end && !exhausted) {  // chunk used up: claim the next one
+            uint32_t c = n_chunks;
+            while (ranges_done < 8u) {   // (one returning atomic per wave and chunk, and one more per range a wave finds used up)
+                const uint32_t x = (xcc + ranges_done) & 7u;
+                const uint32_t lo = (uint32_t)(((uint64_t)n_chunks * x) >> 3), hi = (uint32_t)(((uint64_t)n_chunks * (x + 1u)) >> 3);
+                uint32_t k = 0;
+                if (lane_id() == 0) k = atomicAdd(work + x * CSTRIDE, 1u);
+                k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                if (k < hi - lo) { c = lo + k; break; }
+                ++ranges_done;
+            }
             if (c < n_chunks) {
                 const uint32_t first_tile = c * DYN_TILES;
                 const uint32_t tiles = m.total - first_tile < DYN_TILES ? m.total - first_tile : DYN_TILES;
