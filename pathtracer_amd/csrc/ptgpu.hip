@@ -388,7 +388,7 @@ uint32_t round_up(uint64_t x, uint32_t m) { return (uint32_t)(((x + m - 1) / m) 
 // otherwise idle GPU, and a longer launch dilutes that tail better than a second pass fills it (1M-rectangle field at
 // 1080p: one pass of 64 spp 7 550 Mrays/s, one of 32 spp 7 140, two of 16 spp 6 890, three of 8 spp 6 410) - plus two SMALL
 // ones that only passes of a few samples use: the window loop's frames of one sample, of which three in flight take
-// 1.22 ms each at 1080p where one in flight takes 2.08 (a launch of 2M rays is nearly all tail).  (Three pipes and the
+// 1.10 ms each at 1080p where one in flight takes 2.1 (a launch of 2M rays is nearly all tail).  (Three pipes and the
 // copy stream are four streams, as many as a process gets hardware queues; a fourth pipe would share one, and costs.)
 constexpr uint32_t SMALL_PIPE_SPP = 4;
 int big_pipes_wanted(const PtHandle *h) {
